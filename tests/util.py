@@ -1,0 +1,140 @@
+"""Shared test helpers: synthetic graphs in the reference's index convention and
+seeded operator inputs in the reference's own synthetic distribution.
+
+Index convention (script/train/train_gatconv.py:78-94): CSR rows = destination
+nodes, columns = source nodes ascending; CSC of the same matrix; permute[i] =
+CSR position of the i-th CSC entry.  Built here with scipy exactly as the
+reference script does, so the device/oracle transposes can be checked bit-exact
+against it.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+RTOL = 1e-5   # BASELINE.json north_star: "within rel 1e-5 / abs 1e-6 fp32"
+ATOL = 1e-6
+
+
+def graph_from_edges(n, dst, src):
+    """dst/src: int arrays of directed edges src->dst (duplicates are merged)."""
+    dst = np.asarray(dst, np.int64)
+    src = np.asarray(src, np.int64)
+    key = np.unique(dst * n + src)
+    dst, src = key // n, key % n
+    nnz = dst.shape[0]
+    numlist = np.arange(nnz, dtype=np.int32)
+    adj_csr = sp.csr_matrix((numlist, (dst, src)), shape=(n, n))      # train_gatconv.py:82
+    row_ptr = adj_csr.indptr.astype(np.int32)
+    col_ind = adj_csr.indices.astype(np.int32)
+    adj_csc = adj_csr.tocsc()                                         # :87
+    col_ptr = adj_csc.indptr.astype(np.int32)
+    row_ind = adj_csc.indices.astype(np.int32)
+    adj_csr_new = sp.csr_matrix((numlist, col_ind, row_ptr), shape=(n, n))  # :92
+    permute = adj_csr_new.tocsc().data.astype(np.int32)              # :93-94
+    return dict(n=n, nnz=nnz, row_ptr=row_ptr, col_ind=col_ind, col_ptr=col_ptr,
+                row_ind=row_ind, permute=permute)
+
+
+def random_graph(n, n_edges, seed, self_loops=True, extra=None):
+    rng = np.random.default_rng(seed)
+    dst = rng.integers(0, n, n_edges)
+    src = rng.integers(0, n, n_edges)
+    if self_loops:
+        dst = np.concatenate([dst, np.arange(n)])
+        src = np.concatenate([src, np.arange(n)])
+    if extra is not None:
+        dst = np.concatenate([dst, extra[0]])
+        src = np.concatenate([src, extra[1]])
+    return graph_from_edges(n, dst, src)
+
+
+def tiny_graph():
+    """5 nodes, node 3 has no incoming edge (empty CSR row), node 1 has a self loop,
+    node 4 has no outgoing edge (empty CSC column)."""
+    dst = [0, 0, 1, 1, 2, 4, 4, 4]
+    src = [1, 2, 1, 3, 0, 0, 2, 3]
+    return graph_from_edges(5, dst, src)
+
+
+def degree_graph(n, degrees, seed):
+    """Row r gets exactly degrees[r] distinct sources (degrees[r] <= n)."""
+    rng = np.random.default_rng(seed)
+    dst, src = [], []
+    for r, d in enumerate(degrees):
+        s = rng.choice(n, size=d, replace=False)
+        dst += [r] * d
+        src += list(s)
+    return graph_from_edges(n, dst, src)
+
+
+def powerlaw_graph(n, seed, hub_degree=200):
+    rng = np.random.default_rng(seed)
+    deg = np.minimum((rng.pareto(1.5, n) * 2 + 1).astype(np.int64), n // 2)
+    deg[7] = hub_degree           # one long row
+    deg[11] = 0                   # one empty row
+    g_dst, g_src = [], []
+    # skewed sources so that a few CSC columns are long too
+    p = 1.0 / (np.arange(n) + 1.0)
+    p /= p.sum()
+    for r in range(n):
+        s = rng.choice(n, size=int(deg[r]), replace=False, p=p)
+        g_dst += [r] * int(deg[r])
+        g_src += list(s)
+    return graph_from_edges(n, g_dst, g_src)
+
+
+def rmat_graph(scale, n, n_edges, seed, abcd=(0.57, 0.19, 0.19, 0.05)):
+    """Small R-MAT in numpy (SURVEY 8d synthetic inputs): ids folded to n by `mod n`,
+    self loops added."""
+    rng = np.random.default_rng(seed)
+    a, b, c, _ = abcd
+    dst = np.zeros(n_edges, np.int64)
+    src = np.zeros(n_edges, np.int64)
+    for _lvl in range(scale):
+        u = rng.random(n_edges)
+        dbit = (u >= a + b).astype(np.int64)                       # c or d quadrant
+        sbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.int64)
+        dst = dst * 2 + dbit
+        src = src * 2 + sbit
+    dst %= n
+    src %= n
+    dst = np.concatenate([dst, np.arange(n)])
+    src = np.concatenate([src, np.arange(n)])
+    return graph_from_edges(n, dst, src)
+
+
+def named_graphs():
+    """The edge-case set of SURVEY section 4/8c: empty rows, degree 32/64/65,
+    degree > 64, one long row, tiny graph."""
+    return {
+        "tiny": tiny_graph(),
+        "er64": random_graph(64, 400, 1),
+        "deg_edges": degree_graph(96, [0, 1, 31, 32, 33, 63, 64, 65, 0, 2, 96, 5] + [3] * 84, 2),
+        "powerlaw256": powerlaw_graph(256, 3),
+        "noselfloop": random_graph(50, 120, 4, self_loops=False),
+    }
+
+
+def gat_inputs(n, h, f, seed):
+    """Value distribution of the reference's own synthetic test
+    (script/test/test_gat_tb.py:100-102)."""
+    rng = np.random.default_rng(seed)
+    in_feat = (rng.random((n, h, f), dtype=np.float32) - 0.4).astype(np.float32)
+    attn_row = (rng.random((n, h), dtype=np.float32) - 0.6).astype(np.float32)
+    attn_col = (rng.random((n, h), dtype=np.float32) - 0.4).astype(np.float32)
+    grad = (rng.random((n, h, f), dtype=np.float32) - 0.5).astype(np.float32)
+    return in_feat, attn_row, attn_col, grad
+
+
+def assert_close(actual, expected64, what="", rtol=RTOL, atol=ATOL):
+    """|actual - expected| <= atol + rtol*|expected| elementwise, expected in float64."""
+    a = np.asarray(actual, np.float64)
+    e = np.asarray(expected64, np.float64)
+    assert a.shape == e.shape, f"{what}: shape {a.shape} vs {e.shape}"
+    err = np.abs(a - e)
+    tol = atol + rtol * np.abs(e)
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(
+            f"{what}: {bad.sum()} / {bad.size} outside rel {rtol} abs {atol}; worst at {i}: "
+            f"got {a[i]!r} want {e[i]!r} (err {err[i]:.3e}, tol {tol[i]:.3e})")
