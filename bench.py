@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused GATConv forward+backward on an ogbn-products-shaped R-MAT graph.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|reddit|cora]
+
+A "step" is one GATConvFuse forward + backward (the autograd operator, allocations included)
+over the whole graph with inputs already resident in HBM.  Prints ONE JSON line (rank 0) with
+BASELINE.json's metric (edges/s), the HBM roofline of the dominant kernel and a CPU baseline
+(the oracle's float32 restatement of the reference kernels, timed on the host cores).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the same graph is row-partitioned
+across ranks with RCCL all-gathers of the boundary-node features (dgnn_amd/dist.py); the work
+is fixed, so scaling is "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (nodes, unique directed edges incl. self loops, rmat scale)   SURVEY.md section 8(d)
+    "products": (2_449_029, 62_000_000, 22),
+    "reddit": (232_965, 114_848_857, 18),
+    "cora": (2_708, 13_264, 12),
+}
+H, F = 4, 64
+SLOPE = 0.2
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def rmat_edges(n, target, scale, device, seed, abcd=(0.57, 0.19, 0.19, 0.05)):
+    """Unique directed R-MAT edges (ids folded by mod n) + every self loop, as sorted int64 keys
+    dst*n+src.  Exactly `target` keys are returned."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    a, b, c, _ = abcd
+    want_rand = target - n
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    while keys.numel() < want_rand:
+        batch = int((want_rand - keys.numel()) * 1.35) + 1024
+        dst = torch.zeros(batch, dtype=torch.int64, device=device)
+        src = torch.zeros(batch, dtype=torch.int64, device=device)
+        for _ in range(scale):
+            u = torch.rand(batch, device=device, generator=gen)
+            dbit = (u >= a + b)
+            sbit = ((u >= a) & (u < a + b)) | (u >= a + b + c)
+            dst = dst * 2 + dbit
+            src = src * 2 + sbit
+        dst %= n
+        src %= n
+        k = dst * n + src
+        k = k[dst != src]
+        keys = torch.unique(torch.cat([keys, k]))
+        del dst, src, k, u, dbit, sbit
+    if keys.numel() > want_rand:
+        perm = torch.randperm(keys.numel(), device=device, generator=gen)[:want_rand]
+        keys = keys[perm]
+    loops = torch.arange(n, dtype=torch.int64, device=device) * (n + 1)
+    keys = torch.sort(torch.cat([keys, loops])).values
+    return keys
+
+
+def build_graph(name, device, seed=0):
+    """CSR by destination / CSC / permute in the reference's convention
+    (script/train/train_gatconv.py:78-94), built on the device."""
+    import dgnn_amd
+    from dgnn_amd.native import format_conversion
+    n, target, scale = WORKLOADS[name]
+    keys = rmat_edges(n, target, scale, device, seed)
+    dst = keys // n
+    col_ind = (keys % n).to(torch.int32)
+    counts = torch.bincount(dst, minlength=n)
+    row_ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(counts, 0)
+    row_ptr = row_ptr.to(torch.int32)
+    del keys, dst, counts
+    col_ptr, row_ind, permute = format_conversion.csr2csc_int(row_ptr, col_ind)
+    torch.cuda.synchronize()
+    return dict(n=n, nnz=int(col_ind.numel()), row_ptr=row_ptr, col_ind=col_ind, col_ptr=col_ptr,
+                row_ind=row_ind, permute=permute)
+
+
+def algorithmic_bytes(n, nnz, h, f):
+    """SURVEY.md section 8(d) gather model (attn_drop = 0).  Returns per-phase byte counts."""
+    hf = h * f
+    fwd = nnz * (4 * hf + 4 * h + 4) + n * (4 * hf + 16 * h + 4)          # gather + out + stats
+    # backward, one gather pass: grad rows + packed row stats + row_ind/permute + dE write,
+    # per node in_feat row + grad_feat write + pointers/scalars
+    bwd_csc = nnz * (4 * hf + 16 * h + 8 + 4 * h) + n * (8 * hf + 8 * h + 4)
+    total_model = nnz * (12 * hf + 28 * h + 12) + n * (12 * hf + 36 * h + 8)  # BASELINE.md formula
+    return dict(fwd=fwd, bwd_csc=bwd_csc, survey_total=total_model)
+
+
+def cpu_baseline(name, seed=0):
+    """The oracle (float32 restatement of the reference kernels, OpenMP over rows) timed on the
+    host cores on a bounded sample: an R-MAT graph of the same shape family scaled down so the
+    run takes seconds.  kind = "port" (the reference has no CPU path)."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import gat_inputs, rmat_graph
+    n, target, scale = WORKLOADS[name]
+    div = 64 if name != "cora" else 1
+    ns, es, sc = max(n // div, 64), max(target // div, 256), max(scale - 6, 8) if div > 1 else scale
+    g = rmat_graph(sc, ns, max(es - ns, 1), seed)
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], H, F, seed)
+    cores = min(oracle.max_threads(), 16)
+    oracle.set_threads(cores)
+    t0 = time.perf_counter()
+    out, emax, esum = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], SLOPE, in_feat, 0.0)
+    oracle.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"],
+                        emax, esum, None, in_feat, attn_row, attn_col, grad)
+    dt = time.perf_counter() - t0
+    oracle.set_threads(1)
+    return {"value": g["nnz"] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"oracle f32 fwd+bwd on a 1/{div} scale R-MAT of the same shape "
+                      f"(n={g['n']}, nnz={g['nnz']}, {H}x{F}), {dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="products", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    import dgnn_amd  # noqa: F401
+    from dgnn_amd.operators import GATConvFuse
+
+    g = build_graph(args.workload, device, seed=0)
+    n, nnz = g["n"], g["nnz"]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    # value distribution of the reference's synthetic test (script/test/test_gat_tb.py:100-102)
+    in_feat = (torch.rand((n, H, F), device=device, generator=gen) - 0.4)
+    attn_row = (torch.rand((n, H), device=device, generator=gen) - 0.6)
+    attn_col = (torch.rand((n, H), device=device, generator=gen) - 0.4)
+    grad_out = (torch.rand((n, H, F), device=device, generator=gen) - 0.5)
+
+    if world > 1:
+        from dgnn_amd.dist import PartitionedGAT
+        runner = PartitionedGAT(g, world, rank, device)
+        step_fn = lambda: runner.step(in_feat, attn_row, attn_col, grad_out, SLOPE)
+    else:
+        x = in_feat.requires_grad_()
+        ar = attn_row.requires_grad_()
+        ac = attn_col.requires_grad_()
+
+        def step_fn():
+            x.grad = ar.grad = ac.grad = None
+            out = GATConvFuse(ar, ac, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                              g["permute"], SLOPE, x, 0.0)
+            out.backward(grad_out)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step_fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_fn()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # Per-phase timing with events on the launch stream (torch's current stream), single GPU:
+    # the forward call and the backward call each are dominated by one gather kernel.
+    roof = None
+    if world == 1:
+        from dgnn_amd.native import fused_gatconv
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf = tb = 0.0
+        reps = max(3, min(args.steps, 10))
+        xd, ard, acd = in_feat.detach(), attn_row.detach(), attn_col.detach()
+        for _ in range(reps):
+            ev[0].record()
+            out, emax, esum, emask = fused_gatconv.gat_forward(ard, acd, g["row_ptr"], g["col_ind"], SLOPE, xd, 0.0)
+            ev[1].record()
+            fused_gatconv.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                                       g["permute"], emax, esum, emask, xd, ard, acd, grad_out, out_feat=out)
+            ev[2].record()
+            torch.cuda.synchronize()
+            tf += ev[0].elapsed_time(ev[1])
+            tb += ev[1].elapsed_time(ev[2])
+        tf /= reps
+        tb /= reps
+        ab = algorithmic_bytes(n, nnz, H, F)
+        dom = ("gat_backward (CSC gather pass)", ab["bwd_csc"], tb) if tb >= tf else \
+              ("gat_forward (CSR gather pass)", ab["fwd"], tf)
+        achieved = dom[1] / (dom[2] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom[0],
+                "algorithmic_bytes": dom[1], "ms": round(dom[2], 3),
+                "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
+                "fwd_GBps": round(ab["fwd"] / (tf * 1e-3) / 1e9, 1),
+                "bwd_GBps": round(ab["bwd_csc"] / (tb * 1e-3) / 1e9, 1),
+                "survey_model_GBps": round(ab["survey_total"] / (ms_per_step * 1e-3) / 1e9, 1)}
+
+    if rank == 0:
+        line = {
+            "metric": "GATConv fwd+bwd edges/s", "value": nnz / (ms_per_step * 1e-3), "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
+                                   f"attn_drop=0, fused GATConvFuse fwd+bwd",
+                       "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, RCCL all-gather"},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""ctypes binding of ``libdgnn_hip.so`` (C ABI: ``include/dgnn_hip.h``).
+
+PyTorch is plumbing here: it owns device memory (outputs and workspaces come from its
+caching allocator) and the current HIP stream; every operator runs in the hand-written HIP
+kernels behind the C ABI.  There is NO CPU or eager fallback: if the library is missing, or
+a tensor is not on a GPU, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdgnn_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/dgnn_hip.h declares.
+SIGNATURES = {
+    "dgnn_abi_version": (_i, []),
+    "dgnn_error_string": (ctypes.c_char_p, [_i]),
+    "dgnn_gat_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dgnn_gat_forward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp, _sz, _vp]),
+    "dgnn_gat_inference": (_i, [_i, _i, _i, _i, _f] + [_vp] * 6 + [_vp, _sz, _vp]),
+    "dgnn_gat_forward_tiles": (_i, [_i, _i, _i, _i, _f] + [_vp] * 6 + [_i] + [_vp] * 3 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 16 + [_vp, _sz, _vp]),
+    "dgnn_spmm_csr_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dgnn_spmm_csr": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
+    "dgnn_mhsddmm": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp]),
+    "dgnn_mhtranspose": (_i, [_i, _i] + [_vp] * 3 + [_vp]),
+    "dgnn_gmm_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dgnn_gmm_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),
+    "dgnn_gaussian": (_i, [_i, _i, _i] + [_vp] * 4 + [_vp]),
+    "dgnn_gaussian_backward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dgnn_gaussian_backward": (_i, [_i, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),
+    "dgnn_edgeconv_forward": (_i, [_i, _i, _i] + [_vp] * 6 + [_vp]),
+    "dgnn_edgeconv_backward": (_i, [_i, _i] + [_vp] * 3 + [_vp]),
+    "dgnn_csr2csc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dgnn_csr2csc": (_i, [_i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
+    "dgnn_coo2csr": (_i, [_i, _i] + [_vp] * 2 + [_vp]),
+}
+
+_lib = None
+
+
+class DgnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdgnn_hip.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DgnnError(
+                f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C dgnn_amd/csrc).  dgnn_amd has no CPU/eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dgnn_error_string(int(rc))
+        raise DgnnError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def f32(t, name, ndim=None):
+    """Reference bindings assert CUDA + float32 + contiguous (fused_gatconv.cpp:15-29)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DgnnError(f"{name} must be a GPU tensor (dgnn_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise DgnnError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise DgnnError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise DgnnError(f"{name} must have {ndim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def i32(t, name, ndim=1):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DgnnError(f"{name} must be a GPU tensor (dgnn_amd has no CPU path)")
+    if t.dtype != torch.int32:
+        raise DgnnError(f"{name} must be int32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise DgnnError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise DgnnError(f"{name} must have {ndim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def p(t):
+    """Device pointer (or NULL for None / empty tensors)."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def workspace(nbytes, like):
+    """Scratch from torch's caching allocator (stream-ordered reuse on the current stream)."""
+    if nbytes == 0:
+        return None
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=like.device)

@@ -1,0 +1,113 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libdgnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dgnn_hip.h"
+
+#define DGNN_WAVE 64
+#define DGNN_BLOCK 256                       // 4 waves per workgroup
+#define DGNN_WAVES_PER_BLOCK (DGNN_BLOCK / DGNN_WAVE)
+#define DGNN_NEG_INIT (-1e38f)               // fused_gatconv_kernel.cu:45  `float weightMax = -1e38`
+
+#define DGNN_LAUNCH_CHECK()                         \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+namespace dgnn {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (DGNN_WAVE - 1); }
+__device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
+
+// fused_gatconv_kernel.cu:13  LeakyRelu(x, s) = x > 0 ? x : x*s
+__device__ __forceinline__ float leaky_relu(float x, float s) { return (x > 0.f) ? x : x * s; }
+
+// ---- cross-lane reductions over the full 64-lane wave -----------------------------------
+// DPP row operations do the 16-lane part in the VALU (no LDS traffic); the four row results
+// are then combined through v_readlane.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#define DGNN_DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define DGNN_DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define DGNN_DPP_ROW_HALF_MIRROR 0x141
+#define DGNN_DPP_ROW_MIRROR 0x140
+
+struct OpSum {
+  __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+struct OpMax {
+  __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
+};
+
+// Reduce inside each aligned group of 16 lanes (one DPP row); every lane of the row gets the result.
+template <class Op>
+__device__ __forceinline__ float row16_reduce(float v, Op op) {
+  v = op(v, dpp_f32<DGNN_DPP_QUAD_XOR1>(v));
+  v = op(v, dpp_f32<DGNN_DPP_QUAD_XOR2>(v));
+  v = op(v, dpp_f32<DGNN_DPP_ROW_HALF_MIRROR>(v));
+  v = op(v, dpp_f32<DGNN_DPP_ROW_MIRROR>(v));
+  return v;
+}
+
+// Full-wave reduction; the result is wave-uniform.
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+  v = row16_reduce(v, op);
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, OpSum()); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, OpMax()); }
+
+// Reduce over aligned groups of W lanes (W power of two, 1..64); every lane gets its group's result.
+template <class Op>
+__device__ __forceinline__ float group_reduce(float v, int w, Op op) {
+  if (w >= 2) v = op(v, dpp_f32<DGNN_DPP_QUAD_XOR1>(v));
+  if (w >= 4) v = op(v, dpp_f32<DGNN_DPP_QUAD_XOR2>(v));
+  if (w >= 8) v = op(v, dpp_f32<DGNN_DPP_ROW_HALF_MIRROR>(v));
+  if (w >= 16) v = op(v, dpp_f32<DGNN_DPP_ROW_MIRROR>(v));
+  if (w >= 32) v = op(v, __shfl_xor(v, 16, DGNN_WAVE));
+  if (w >= 64) v = op(v, __shfl_xor(v, 32, DGNN_WAVE));
+  return v;
+}
+
+// Broadcast lane `src` (wave-uniform index) of v to every lane.
+__device__ __forceinline__ float bcast_f32(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+// Make a value the compiler cannot prove uniform into an SGPR value (it IS uniform by construction).
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// Order LDS traffic between lanes of ONE wave (no workgroup barrier is needed: each wave owns
+// its LDS slice).  Emits at most an s_waitcnt.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Dropout scaling exactly as the reference writes it: weight / (1.0 - attn_drop) in double
+// (fused_gatconv_kernel.cu:104).
+__device__ __forceinline__ float drop_scale(float w, float attn_drop) {
+  return (float)((double)w / (1.0 - (double)attn_drop));
+}
+
+static inline int blocks_for_waves(long long n_waves) {
+  return (int)((n_waves + DGNN_WAVES_PER_BLOCK - 1) / DGNN_WAVES_PER_BLOCK);
+}
+
+}  // namespace dgnn

@@ -1,0 +1,120 @@
+// Device-side index work: CSR -> CSC with permutation (stable), sorted COO -> CSR.
+// Replaces the cuSPARSE calls of dgNN/src/convert/convert_kernel.cu:6-59 and the host scipy
+// path of script/train/train_gatconv.py:87-94.  The stable sort by column is rocPRIM's LSD
+// radix sort (index plumbing, not a hot kernel); everything else is hand-written.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "common.hpp"
+
+using namespace dgnn;
+
+namespace dgnn {
+
+__device__ __forceinline__ int lower_bound_i32(const int *__restrict__ a, int n, int key) {
+  int lo = 0, hi = n;  // first index with a[idx] >= key
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ptr[c] = number of sorted keys < c, for c in [0, n]
+__global__ void k_ptr_from_sorted(int n, int nnz, const int *__restrict__ sorted_keys,
+                                  int *__restrict__ ptr) {
+  for (long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x; c <= n;
+       c += (long long)gridDim.x * blockDim.x)
+    ptr[c] = lower_bound_i32(sorted_keys, nnz, (int)c);
+}
+
+// row_ind[i] = row that owns CSR position permute[i]: last r with row_ptr[r] <= pos
+__global__ void k_rows_of_positions(int m, int nnz, const int *__restrict__ row_ptr,
+                                    const int *__restrict__ permute, int *__restrict__ row_ind) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int pos = permute[i];
+    int lo = 0, hi = m;  // invariant: row_ptr[lo] <= pos < row_ptr[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (row_ptr[mid] <= pos) lo = mid; else hi = mid;
+    }
+    row_ind[i] = lo;
+  }
+}
+
+static inline int grid_1d(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  const long long cap = 256LL * 32;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+static inline int key_bits(int n) {
+  int b = 1;
+  while (b < 31 && (1LL << b) < (long long)n) ++b;
+  return b;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static hipError_t sort_temp_bytes(int nnz, int bits, size_t *bytes) {
+  *bytes = 0;
+  return rocprim::radix_sort_pairs(nullptr, *bytes, (const int *)nullptr, (int *)nullptr,
+                                   rocprim::counting_iterator<int>(0), (int *)nullptr,
+                                   (size_t)nnz, 0, bits, (hipStream_t)0);
+}
+
+}  // namespace dgnn
+
+extern "C" {
+
+size_t dgnn_csr2csc_workspace_bytes(int m, int n, int nnz) {
+  (void)m;
+  if (nnz <= 0 || n <= 0) return 0;
+  size_t temp = 0;
+  if (sort_temp_bytes(nnz, key_bits(n), &temp) != hipSuccess) return 0;
+  return align_up(sizeof(int) * (size_t)nnz, 256) + align_up(temp, 256);
+}
+
+int dgnn_csr2csc(int m, int n, int nnz, const int *row_ptr, const int *col_ind, int *col_ptr,
+                 int *row_ind, int *permute, void *workspace, size_t workspace_bytes,
+                 void *stream) {
+  if (m < 0 || n < 0 || nnz < 0) return DGNN_ERR_BAD_ARG;
+  if (!row_ptr || !col_ptr) return DGNN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (nnz == 0) {
+    hipError_t e = hipMemsetAsync(col_ptr, 0, sizeof(int) * ((size_t)n + 1), st);
+    return e == hipSuccess ? DGNN_OK : (int)e;
+  }
+  if (!col_ind || !row_ind || !permute) return DGNN_ERR_BAD_ARG;
+  const int bits = key_bits(n);
+  size_t temp = 0;
+  hipError_t e = sort_temp_bytes(nnz, bits, &temp);
+  if (e != hipSuccess) return (int)e;
+  const size_t keys_bytes = align_up(sizeof(int) * (size_t)nnz, 256);
+  if (!workspace || workspace_bytes < keys_bytes + align_up(temp, 256)) return DGNN_ERR_WORKSPACE;
+  int *sorted_keys = (int *)workspace;
+  void *sort_tmp = (char *)workspace + keys_bytes;
+  // stable sort of (column, CSR position): positions of one column stay ascending, i.e. rows ascending
+  e = rocprim::radix_sort_pairs(sort_tmp, temp, col_ind, sorted_keys,
+                                rocprim::counting_iterator<int>(0), permute, (size_t)nnz, 0, bits, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_1d((long long)n + 1, 256)), dim3(256), 0, st, n,
+                     nnz, (const int *)sorted_keys, col_ptr);
+  DGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rows_of_positions, dim3(grid_1d(nnz, 256)), dim3(256), 0, st, m, nnz,
+                     row_ptr, (const int *)permute, row_ind);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_coo2csr(int m, int nnz, const int *coo_row, int *row_ptr, void *stream) {
+  if (m < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !coo_row)) return DGNN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_1d((long long)m + 1, 256)), dim3(256), 0,
+                     (hipStream_t)stream, m, nnz, coo_row, row_ptr);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+}  // extern "C"

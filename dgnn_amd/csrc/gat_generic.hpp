@@ -1,0 +1,225 @@
+// Generic (any H, any F) fused-GAT kernels: one wave64 per CSR row / CSC column.
+// These are the shape-agnostic fallback; the neighbour-grouped fast path lives in
+// gat_fast.hpp and is used whenever its layout constraints hold (see gat.hip).
+#pragma once
+#include "common.hpp"
+
+namespace dgnn {
+
+// Forward.  Semantics of fused_forward_kernel (fused_gatconv_kernel.cu:24-118): row max of
+// LeakyReLU(attn_row[r,h]+attn_col[c,h]) from -1e38, sum of exp(e-max), then
+// out[r,h,:] = sum_j [mask_j > p] * exp(e_j-max)/sum / (1.0-p) * in_feat[c_j,h,:].
+// edge_max/edge_sum may be NULL (inference).  edge_mask may be NULL (keep all).
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_fwd_row(
+    int m, int H, int F, float attn_drop, float slope, const float *__restrict__ attn_row,
+    const float *__restrict__ attn_col, const int *__restrict__ row_ptr,
+    const int *__restrict__ col_ind, const float *__restrict__ in_feat,
+    const float *__restrict__ edge_mask, float *__restrict__ edge_max,
+    float *__restrict__ edge_sum, float *__restrict__ out) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= m) return;
+  const int lane = lane_id();
+  const int lb = row_ptr[r], hb = row_ptr[r + 1];
+  const size_t HF = (size_t)H * F;
+  for (int h = 0; h < H; ++h) {
+    const float ar = attn_row[(size_t)r * H + h];
+    float mx = DGNN_NEG_INIT;
+    for (int p = lb + lane; p < hb; p += DGNN_WAVE)
+      mx = fmaxf(mx, leaky_relu(ar + attn_col[(size_t)col_ind[p] * H + h], slope));
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int p = lb + lane; p < hb; p += DGNN_WAVE)
+      sm += expf(leaky_relu(ar + attn_col[(size_t)col_ind[p] * H + h], slope) - mx);
+    sm = wave_sum(sm);
+    if (edge_max != nullptr && lane == 0) {
+      edge_max[(size_t)r * H + h] = mx;
+      edge_sum[(size_t)r * H + h] = sm;
+    }
+    for (int fb = 0; fb < F; fb += DGNN_WAVE) {
+      const int fid = fb + lane;
+      float acc = 0.f;
+      for (int base = lb; base < hb; base += DGNN_WAVE) {
+        const int p = base + lane;
+        float w = 0.f;
+        int c = 0;
+        if (p < hb) {
+          c = col_ind[p];
+          const bool keep = (edge_mask == nullptr) || (edge_mask[(size_t)p * H + h] > attn_drop);
+          if (keep) w = expf(leaky_relu(ar + attn_col[(size_t)c * H + h], slope) - mx) / sm;
+          if (attn_drop > 0.f) w = drop_scale(w, attn_drop);
+        }
+        const int n = min(DGNN_WAVE, hb - base);
+        for (int k = 0; k < n; ++k) {
+          const int ck = bcast_i32(c, k);
+          const float wk = bcast_f32(w, k);
+          if (fid < F) acc = fmaf(wk, in_feat[(size_t)ck * HF + (size_t)h * F + fid], acc);
+        }
+      }
+      if (fid < F) out[(size_t)r * HF + (size_t)h * F + fid] = acc;
+    }
+  }
+}
+
+// S[r,h] = <grad[r,h,:], out[r,h,:]>.  Equals the row term sum_j a_j g_j that
+// fused_backward_kernel builds in its first sweep (fused_gatconv_kernel.cu:906-931), because
+// out[r,h,:] = sum_j a_j*mask_j/(1-p) * in_feat[c_j,h,:] and g_j = mask_j/(1-p) * <grad[r],in_feat[c_j]>.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_dot(int m, int H, int F,
+                                                            const float *__restrict__ grad,
+                                                            const float *__restrict__ out,
+                                                            float *__restrict__ S) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= m) return;
+  const int lane = lane_id();
+  const size_t HF = (size_t)H * F;
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int c = lane; c < F; c += DGNN_WAVE)
+      s = fmaf(grad[(size_t)r * HF + (size_t)h * F + c], out[(size_t)r * HF + (size_t)h * F + c], s);
+    s = wave_sum(s);
+    if (lane == 0) S[(size_t)r * H + h] = s;
+  }
+}
+
+// Transposed (CSC) pass, one wave per source column c.  Fuses mhspmm_backward_kernel
+// (:712-763, grad_feat), the SDDMM of mhsddmm (:814-890, edge dot products, here against the
+// column's own in_feat row) and the per-edge part of fused_backward_kernel (:934-958):
+//   a   = exp(LeakyReLU(attn_row[r]+attn_col[c]) - edge_max[r]) / edge_sum[r]
+//   g   = [mask>p]/(1.0-p) * <grad[r,h,:], in_feat[c,h,:]>
+//   d   = a * (g - S[r,h]) * (e < 0 ? slope : 1)
+//   grad_feat[c,h,:]   = sum_i [mask>p] a_i/(1-p) * grad[r_i,h,:]
+//   grad_attn_col[c,h] = sum_i d_i            (a plain sum: no atomics, deterministic)
+//   dE[permute[i],h]   = d_i                  (CSR-ordered, summed per row by k_gat_row_sum)
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_bwd_col(
+    int n, int H, int F, float slope, float attn_drop, const int *__restrict__ col_ptr,
+    const int *__restrict__ row_ind, const int *__restrict__ permute,
+    const float *__restrict__ edge_max, const float *__restrict__ edge_sum,
+    const float *__restrict__ edge_mask, const float *__restrict__ attn_row,
+    const float *__restrict__ attn_col, const float *__restrict__ in_feat,
+    const float *__restrict__ grad, const float *__restrict__ S, float *__restrict__ dE,
+    float *__restrict__ grad_feat, float *__restrict__ grad_attn_col) {
+  const int c = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (c >= n) return;
+  const int lane = lane_id();
+  const int lb = col_ptr[c], hb = col_ptr[c + 1];
+  const size_t HF = (size_t)H * F;
+  for (int h = 0; h < H; ++h) {
+    const float ac = attn_col[(size_t)c * H + h];
+    const float *u = in_feat + (size_t)c * HF + (size_t)h * F;
+    float dsum = 0.f;
+    for (int base = lb; base < hb; base += DGNN_WAVE) {
+      const int p = base + lane;
+      int rid = 0, pos = 0;
+      float a = 0.f, e = 0.f, Sv = 0.f;
+      bool keep = false;
+      if (p < hb) {
+        rid = row_ind[p];
+        pos = permute[p];
+        e = leaky_relu(attn_row[(size_t)rid * H + h] + ac, slope);
+        a = expf(e - edge_max[(size_t)rid * H + h]) / edge_sum[(size_t)rid * H + h];
+        keep = (edge_mask == nullptr) || (edge_mask[(size_t)pos * H + h] > attn_drop);
+        Sv = S[(size_t)rid * H + h];
+      }
+      const int cnt = min(DGNN_WAVE, hb - base);
+      float mydot = 0.f;
+      for (int k = 0; k < cnt; ++k) {
+        const int rk = bcast_i32(rid, k);
+        const float *g = grad + (size_t)rk * HF + (size_t)h * F;
+        float part = 0.f;
+        for (int q = lane; q < F; q += DGNN_WAVE) part = fmaf(g[q], u[q], part);
+        part = wave_sum(part);
+        if (lane == k) mydot = part;
+      }
+      if (p < hb) {
+        float ge = 0.f;
+        if (keep) ge = (attn_drop > 0.f) ? drop_scale(mydot, attn_drop) : mydot;
+        float d = a * (ge - Sv);
+        if (e < 0.f) d *= slope;
+        dsum += d;
+        dE[(size_t)pos * H + h] = d;
+      }
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0) grad_attn_col[(size_t)c * H + h] = dsum;
+
+    for (int fb = 0; fb < F; fb += DGNN_WAVE) {
+      const int fid = fb + lane;
+      float acc = 0.f;
+      for (int base = lb; base < hb; base += DGNN_WAVE) {
+        const int p = base + lane;
+        int rid = 0;
+        float w = 0.f;
+        if (p < hb) {
+          rid = row_ind[p];
+          const bool keep =
+              (edge_mask == nullptr) || (edge_mask[(size_t)permute[p] * H + h] > attn_drop);
+          if (keep) {
+            const float e = leaky_relu(attn_row[(size_t)rid * H + h] + ac, slope);
+            w = expf(e - edge_max[(size_t)rid * H + h]) / edge_sum[(size_t)rid * H + h];
+          }
+          if (attn_drop > 0.f) w = w / (1 - attn_drop);  // float divide, :749
+        }
+        const int cnt = min(DGNN_WAVE, hb - base);
+        for (int k = 0; k < cnt; ++k) {
+          const int rk = bcast_i32(rid, k);
+          const float wk = bcast_f32(w, k);
+          if (fid < F) acc = fmaf(wk, grad[(size_t)rk * HF + (size_t)h * F + fid], acc);
+        }
+      }
+      if (fid < F) grad_feat[(size_t)c * HF + (size_t)h * F + fid] = acc;
+    }
+  }
+}
+
+// grad_attn_row[r,h] = sum over the row's edges of dE[e,h]  (fused_backward_kernel :961-967).
+// One 16-lane group per row; a row longer than LONG_ROW edges is finished by the whole block.
+#define DGNN_ROWSUM_LONG 4096
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,
+                                                            const int *__restrict__ row_ptr,
+                                                            const float *__restrict__ dE,
+                                                            float *__restrict__ grad_attn_row) {
+  __shared__ float red[DGNN_BLOCK];
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
+  const int r0 = blockIdx.x * 16;
+  const int r = r0 + grp;
+  if (r < m) {
+    const int lb = row_ptr[r], hb = row_ptr[r + 1];
+    if (hb - lb <= DGNN_ROWSUM_LONG) {
+      if (H <= 16 && (16 % H) == 0) {
+        // the 16 lanes walk the row's contiguous [deg*H] slab; since 16 % H == 0 a lane
+        // always lands on head q % H
+        float s = 0.f;
+        const size_t beg = (size_t)lb * H, end = (size_t)hb * H;
+        for (size_t i = beg + q; i < end; i += 16) s += dE[i];
+        for (int st = H; st < 16; st <<= 1) s += __shfl_xor(s, st, 16);
+        if (q < H) grad_attn_row[(size_t)r * H + q] = s;
+      } else {
+        for (int h = q; h < H; h += 16) {
+          float s = 0.f;
+          for (int p = lb; p < hb; ++p) s += dE[(size_t)p * H + h];
+          grad_attn_row[(size_t)r * H + h] = s;
+        }
+      }
+    }
+  }
+  // long rows: the whole block cooperates, fixed reduction tree => deterministic
+  for (int g = 0; g < 16; ++g) {
+    const int rr = r0 + g;
+    if (rr >= m) break;
+    const int lb = row_ptr[rr], hb = row_ptr[rr + 1];
+    if (hb - lb <= DGNN_ROWSUM_LONG) continue;
+    for (int h = 0; h < H; ++h) {
+      float s = 0.f;
+      for (int p = lb + (int)threadIdx.x; p < hb; p += DGNN_BLOCK) s += dE[(size_t)p * H + h];
+      red[threadIdx.x] = s;
+      __syncthreads();
+      for (int st = DGNN_BLOCK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) grad_attn_row[(size_t)rr * H + h] = red[0];
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace dgnn

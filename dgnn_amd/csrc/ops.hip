@@ -1,0 +1,407 @@
+// GE-SpMM, multi-head SDDMM, edge permute, fused GMMConv and fused EdgeConv:
+// kernels + C-ABI entry points (include/dgnn_hip.h).
+#include "common.hpp"
+
+using namespace dgnn;
+
+namespace dgnn {
+
+// --------------------------------------------------------------------------- SpMM / GMM
+// One wave per CSR row.  WEIGHT = 0: caller-supplied edge values (GE-SpMM, phase 3 of
+// fused_gatconv_kernel.cu:87-117).  WEIGHT = 1: Gaussian kernel weight computed on the fly
+// from pseudo coordinates (fuseGmm, fused_gmmconv_kernel.cu:24-55): float accumulation of
+// ((p-mu)^2 * sig^2), exponent in DOUBLE as the reference's `exp(-0.5 * gauss)` (:44).
+__device__ __forceinline__ float gauss_weight(int dim, const float *__restrict__ ps,
+                                              const float *__restrict__ mu,
+                                              const float *__restrict__ isg) {
+  float acc = 0.f;
+  for (int d = 0; d < dim; ++d) {
+    const float tmp = ps[d] - mu[d];
+    const float sig = isg[d];
+    acc = fmaf(tmp * tmp * sig, sig, acc);  // nvcc contracts `gauss += tmp*tmp*sig*sig` the same way
+  }
+  return (float)exp(-0.5 * (double)acc);
+}
+
+template <int WEIGHT>
+__global__ __launch_bounds__(DGNN_BLOCK) void k_spmm_row(
+    int m, int H, int F, int dim, const int *__restrict__ row_ptr,
+    const int *__restrict__ col_ind, const float *__restrict__ edge_val,
+    const float *__restrict__ pseudo, const float *__restrict__ mu,
+    const float *__restrict__ inv_sigma, const float *__restrict__ in_feat,
+    float *__restrict__ out) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= m) return;
+  const int lane = lane_id();
+  const int lb = row_ptr[r], hb = row_ptr[r + 1];
+  const size_t HF = (size_t)H * F;
+  for (int h = 0; h < H; ++h) {
+    for (int fb = 0; fb < F; fb += DGNN_WAVE) {
+      const int fid = fb + lane;
+      float acc = 0.f;
+      for (int base = lb; base < hb; base += DGNN_WAVE) {
+        const int p = base + lane;
+        float w = 0.f;
+        int c = 0;
+        if (p < hb) {
+          c = col_ind[p];
+          if (WEIGHT == 0)
+            w = edge_val[(size_t)p * H + h];
+          else
+            w = gauss_weight(dim, pseudo + (size_t)p * dim, mu + (size_t)h * dim,
+                             inv_sigma + (size_t)h * dim);
+        }
+        const int n = min(DGNN_WAVE, hb - base);
+        for (int k = 0; k < n; ++k) {
+          const int ck = bcast_i32(c, k);
+          const float wk = bcast_f32(w, k);
+          if (fid < F) acc = fmaf(wk, in_feat[(size_t)ck * HF + (size_t)h * F + fid], acc);
+        }
+      }
+      if (fid < F) out[(size_t)r * HF + (size_t)h * F + fid] = acc;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- SDDMM
+// out[e,h] = <A[row(e),h,:], B[col(e),h,:]>  (mhsddmm_kernel.cu:5-81).  One wave per row, so
+// the row operand is read once and no binary search (findRow, computeUtil.h:38-54) is needed.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_row(int v, int H, int F,
+                                                          const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ col_ind,
+                                                          const float *__restrict__ A,
+                                                          const float *__restrict__ B,
+                                                          float *__restrict__ out) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= v) return;
+  const int lane = lane_id();
+  const int lb = row_ptr[r], hb = row_ptr[r + 1];
+  const size_t HF = (size_t)H * F;
+  for (int p = lb; p < hb; ++p) {
+    const int c = uniform_i32(col_ind[p]);
+    for (int h = 0; h < H; ++h) {
+      const float *a = A + (size_t)r * HF + (size_t)h * F;
+      const float *b = B + (size_t)c * HF + (size_t)h * F;
+      float s = 0.f;
+      for (int q = lane; q < F; q += DGNN_WAVE) s = fmaf(a[q], b[q], s);
+      s = wave_sum(s);
+      if (lane == 0) out[(size_t)p * H + h] = s;
+    }
+  }
+}
+
+// out[i,:] = in[permute[i],:]   (mhtranspose_kernel.cu:6-26)
+__global__ void k_mhtranspose(long long total, int H, const int *__restrict__ permute,
+                              const float *__restrict__ in, float *__restrict__ out) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long i = t / H;
+    const int h = (int)(t - i * H);
+    out[t] = in[(size_t)permute[i] * H + h];
+  }
+}
+
+// --------------------------------------------------------------------------- Gaussian
+__global__ void k_gaussian(long long total, int K, int dim, const float *__restrict__ pseudo,
+                           const float *__restrict__ mu, const float *__restrict__ inv_sigma,
+                           float *__restrict__ gauss) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long e = t / K;
+    const int k = (int)(t - e * K);
+    gauss[t] = gauss_weight(dim, pseudo + (size_t)e * dim, mu + (size_t)k * dim,
+                            inv_sigma + (size_t)k * dim);
+  }
+}
+
+// Stage 1 of the Gaussian backward: each thread owns one edge; pseudo_out is written directly,
+// the [K,dim] parameter gradients are reduced per block into partial[block][2][K*dim].
+#define DGNN_GBP_BLOCK 256
+__global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stage1(
+    int edges, int K, int dim, const float *__restrict__ pseudo, const float *__restrict__ mu,
+    const float *__restrict__ inv_sigma, const float *__restrict__ grad_gauss,
+    float *__restrict__ pseudo_out, float *__restrict__ partial) {
+  __shared__ float red[DGNN_GBP_BLOCK / DGNN_WAVE];
+  const int e = blockIdx.x * DGNN_GBP_BLOCK + threadIdx.x;
+  const bool live = e < edges;
+  const int KD = K * dim;
+  for (int d = 0; d < dim; ++d) {
+    if (live) pseudo_out[(size_t)e * dim + d] = 0.f;
+  }
+  for (int k = 0; k < K; ++k) {
+    float g = 0.f;
+    if (live)
+      g = gauss_weight(dim, pseudo + (size_t)e * dim, mu + (size_t)k * dim,
+                       inv_sigma + (size_t)k * dim) *
+          grad_gauss[(size_t)e * K + k];
+    for (int d = 0; d < dim; ++d) {
+      float cm = 0.f, cs = 0.f;
+      if (live) {
+        const float sig = inv_sigma[k * dim + d];
+        const float diff = pseudo[(size_t)e * dim + d] - mu[k * dim + d];
+        const float t = g * diff * sig;
+        pseudo_out[(size_t)e * dim + d] += -t * sig;
+        cm = t * sig;          // d gauss / d mu
+        cs = -g * diff * diff * sig;  // d gauss / d inv_sigma
+      }
+      for (int which = 0; which < 2; ++which) {
+        float v = wave_sum(which == 0 ? cm : cs);
+        if (lane_id() == 0) red[wave_in_block()] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float s = 0.f;
+          for (int w = 0; w < DGNN_GBP_BLOCK / DGNN_WAVE; ++w) s += red[w];
+          partial[((size_t)blockIdx.x * 2 + which) * KD + k * dim + d] = s;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// Stage 2: one block per (which, k*dim+d) sums the per-block partials in a fixed order.
+__global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stage2(
+    int nblocks, int KD, const float *__restrict__ partial, float *__restrict__ mu_out,
+    float *__restrict__ sigma_out) {
+  __shared__ float red[DGNN_GBP_BLOCK];
+  const int which = blockIdx.x / KD, idx = blockIdx.x % KD;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += DGNN_GBP_BLOCK)
+    s += partial[((size_t)b * 2 + which) * KD + idx];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = DGNN_GBP_BLOCK / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) (which == 0 ? mu_out : sigma_out)[idx] = red[0];
+}
+
+// --------------------------------------------------------------------------- EdgeConv
+// One wave per point, one lane per feature column (coalesced h_src row reads).  The arg-max
+// reproduces the reference's 32-lane xor butterfly (`tmp >= feat` takes the partner,
+// fused_edgeconv_kernel.cu:31-38) in closed form: inside a 32-neighbour tile the tied
+// candidate with the LARGEST BIT-REVERSED 5-bit tile position wins; padding lanes of the last
+// tile carry (-1e38, -1) and, holding position 31 (bit-reversal 31), win every tie; a later
+// tile replaces the running best on >= (:39).  max_val starts at -1e39 == -inf (:19).
+__device__ __forceinline__ int bitrev5(int x) { return (int)(__brev((unsigned)x) >> 27); }
+
+__global__ __launch_bounds__(DGNN_BLOCK) void k_edgeconv_fwd(
+    int m, int F, int k, const int *__restrict__ src_ind, const float *__restrict__ h_src,
+    const float *__restrict__ h_dst, float *__restrict__ out_feat, float *__restrict__ idx_f32,
+    int *__restrict__ idx_i32) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= m) return;
+  const int lane = lane_id();
+  const size_t lb = (size_t)r * k;
+  for (int fb = 0; fb < F; fb += DGNN_WAVE) {
+    const int fid = fb + lane;
+    const bool live = fid < F;
+    const float dst_val = live ? h_dst[(size_t)r * F + fid] : 0.f;
+    float max_val = -INFINITY;
+    int max_id = -1;
+    for (int t0 = 0; t0 < k; t0 += 32) {
+      const int cnt = min(32, k - t0);
+      // lanes 0..cnt-1 fetch the tile's neighbour ids once, then broadcast them
+      int my_src = 0;
+      if (lane < cnt) my_src = src_ind[lb + t0 + lane];
+      float bv = 0.f;
+      int bkey = -1, bid = -1;
+      for (int q = 0; q < cnt; ++q) {
+        const int s = bcast_i32(my_src, q);
+        const float v = live ? dst_val + h_src[(size_t)s * F + fid] : 0.f;
+        const int key = bitrev5(q);
+        if (bkey < 0 || v > bv || (v == bv && key > bkey)) {
+          bv = v;
+          bkey = key;
+          bid = s;
+        }
+      }
+      if (cnt < 32 && -1e38f >= bv) {  // padding lanes (:24-25) sit at tile position 31
+        bv = -1e38f;
+        bid = -1;
+      }
+      if (bv >= max_val) {
+        max_val = bv;
+        max_id = bid;
+      }
+    }
+    if (live) {
+      out_feat[(size_t)r * F + fid] = max_val;
+      idx_f32[(size_t)r * F + fid] = (float)max_id;
+      if (idx_i32 != nullptr) idx_i32[(size_t)r * F + fid] = max_id;
+    }
+  }
+}
+
+__global__ void k_edgeconv_bwd(long long total, int F, const int *__restrict__ max_idx,
+                               const float *__restrict__ grad_out, float *__restrict__ grad_src) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int s = max_idx[t];
+    if (s >= 0) atomicAdd(&grad_src[(size_t)s * F + (t % F)], grad_out[t]);
+  }
+}
+
+static inline int grid_1d(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  const long long cap = 256LL * 32;  // grid-stride beyond ~32 blocks per CU
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace dgnn
+
+extern "C" {
+
+int dgnn_abi_version(void) { return 1; }
+
+const char *dgnn_error_string(int code) {
+  switch (code) {
+    case DGNN_OK: return "ok";
+    case DGNN_ERR_BAD_ARG: return "bad argument (negative size or NULL tensor)";
+    case DGNN_ERR_UNSUPPORTED: return "shape not supported";
+    case DGNN_ERR_WORKSPACE: return "workspace missing or too small";
+    case DGNN_ERR_ALIGNMENT: return "pointer not aligned";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dgnn error";
+  }
+}
+
+size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f) {
+  (void)m; (void)nnz; (void)h; (void)f;
+  return 0;
+}
+
+int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                  const float *edge_val, const float *in_feat, float *out_feat, void *workspace,
+                  size_t workspace_bytes, void *stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if (!row_ptr || !in_feat || !out_feat || (nnz > 0 && (!col_ind || !edge_val))) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  hipLaunchKernelGGL(k_spmm_row<0>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, m, h, f, 0, row_ptr, col_ind, edge_val,
+                     (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, in_feat,
+                     out_feat);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_mhsddmm(int v, int f, int h, int nnz, const int *row_ptr, const int *col_ind,
+                 const float *grad, const float *feature, float *out, void *stream) {
+  if (v < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if (!row_ptr || (nnz > 0 && (!col_ind || !grad || !feature || !out))) return DGNN_ERR_BAD_ARG;
+  if (v == 0 || nnz == 0) return DGNN_OK;
+  hipLaunchKernelGGL(k_sddmm_row, dim3(blocks_for_waves(v)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, v, h, f, row_ptr, col_ind, grad, feature, out);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_mhtranspose(int nnz, int h, const int *permute, const float *in, float *out,
+                     void *stream) {
+  if (nnz < 0 || h <= 0) return DGNN_ERR_BAD_ARG;
+  if (nnz == 0) return DGNN_OK;
+  if (!permute || !in || !out) return DGNN_ERR_BAD_ARG;
+  const long long total = (long long)nnz * h;
+  hipLaunchKernelGGL(k_mhtranspose, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     total, h, permute, in, out);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+size_t dgnn_gmm_forward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
+  (void)nodes; (void)nnz; (void)kernels; (void)embed;
+  return 0;
+}
+
+int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
+                     const int *col_ind, const float *node_feat, const float *pseudo,
+                     const float *mu, const float *inv_sigma, float *out, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (nodes < 0 || nnz < 0 || kernels <= 0 || dim <= 0 || embed <= 0) return DGNN_ERR_BAD_ARG;
+  if (!csr_ptr || !node_feat || !mu || !inv_sigma || !out || (nnz > 0 && (!col_ind || !pseudo)))
+    return DGNN_ERR_BAD_ARG;
+  if (nodes == 0) return DGNN_OK;
+  hipLaunchKernelGGL(k_spmm_row<1>, dim3(blocks_for_waves(nodes)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, nodes, kernels, embed, dim, csr_ptr, col_ind,
+                     (const float *)nullptr, pseudo, mu, inv_sigma, node_feat, out);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_gaussian(int edges, int kernels, int dim, const float *pseudo, const float *mu,
+                  const float *inv_sigma, float *gauss, void *stream) {
+  if (edges < 0 || kernels <= 0 || dim <= 0) return DGNN_ERR_BAD_ARG;
+  if (edges == 0) return DGNN_OK;
+  if (!pseudo || !mu || !inv_sigma || !gauss) return DGNN_ERR_BAD_ARG;
+  const long long total = (long long)edges * kernels;
+  hipLaunchKernelGGL(k_gaussian, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     total, kernels, dim, pseudo, mu, inv_sigma, gauss);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+size_t dgnn_gaussian_backward_workspace_bytes(int edges, int kernels, int dim) {
+  if (edges <= 0 || kernels <= 0 || dim <= 0) return 0;
+  const size_t nblocks = ((size_t)edges + DGNN_GBP_BLOCK - 1) / DGNN_GBP_BLOCK;
+  return nblocks * 2 * (size_t)kernels * dim * sizeof(float);
+}
+
+int dgnn_gaussian_backward(int edges, int kernels, int dim, const float *pseudo, const float *mu,
+                           const float *inv_sigma, const float *grad_gauss, float *pseudo_out,
+                           float *mu_out, float *sigma_out, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+  if (edges < 0 || kernels <= 0 || dim <= 0) return DGNN_ERR_BAD_ARG;
+  if (!mu || !inv_sigma || !mu_out || !sigma_out) return DGNN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int KD = kernels * dim;
+  if (edges == 0) {
+    hipError_t e = hipMemsetAsync(mu_out, 0, sizeof(float) * KD, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(sigma_out, 0, sizeof(float) * KD, st);
+    return e == hipSuccess ? DGNN_OK : (int)e;
+  }
+  if (!pseudo || !grad_gauss || !pseudo_out) return DGNN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < dgnn_gaussian_backward_workspace_bytes(edges, kernels, dim))
+    return DGNN_ERR_WORKSPACE;
+  const int nblocks = (edges + DGNN_GBP_BLOCK - 1) / DGNN_GBP_BLOCK;
+  hipLaunchKernelGGL(k_gaussian_bwd_stage1, dim3(nblocks), dim3(DGNN_GBP_BLOCK), 0, st, edges,
+                     kernels, dim, pseudo, mu, inv_sigma, grad_gauss, pseudo_out,
+                     (float *)workspace);
+  DGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gaussian_bwd_stage2, dim3(2 * KD), dim3(DGNN_GBP_BLOCK), 0, st, nblocks, KD,
+                     (const float *)workspace, mu_out, sigma_out);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_edgeconv_forward(int m, int f, int k, const int *src_ind, const float *h_src,
+                          const float *h_dst, float *out_feat, float *max_idx_f32,
+                          int *max_idx_i32, void *stream) {
+  if (m < 0 || f <= 0 || k < 0) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (!h_src || !h_dst || !out_feat || !max_idx_f32 || (k > 0 && !src_ind)) return DGNN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_edgeconv_fwd, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, m, f, k, src_ind, h_src, h_dst, out_feat, max_idx_f32,
+                     max_idx_i32);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_edgeconv_backward(int m, int f, const int *max_idx, const float *grad_out,
+                           float *grad_src, void *stream) {
+  if (m < 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (!max_idx || !grad_out || !grad_src) return DGNN_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)m * f;
+  hipError_t e = hipMemsetAsync(grad_src, 0, sizeof(float) * (size_t)total, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_edgeconv_bwd, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, f, max_idx,
+                     grad_out, grad_src);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+}  // extern "C"

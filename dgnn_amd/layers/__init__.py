@@ -1,0 +1,4 @@
+# Same exports as the reference's dgNN/layers/__init__.py (without its import-time print, :1).
+from .gatconv_layer import GATConv
+from .gmmconv_layer import GMMConv
+from .edgeconv_layer import EdgeConv

@@ -1,0 +1,38 @@
+"""Autograd operator of fused GMMConv.  API of dgNN/operators/fused_gmmconv.py:9-27."""
+import torch
+
+from ..native import fused_gmmconv as gmm
+from ..native import mhsddmm
+from ..native import mhtranspose
+
+
+def GmmConvFuse(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
+    """dgNN/operators/fused_gmmconv.py:9-10; `sigma` is the INVERSE sigma, as in the reference."""
+    return GmmFuseFunction.apply(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma)
+
+
+GMMConvFuse = GmmConvFuse   # spelling used by BASELINE.json's north_star
+
+
+class GmmFuseFunction(torch.autograd.Function):
+    """dgNN/operators/fused_gmmconv.py:12-27: forward gmmconv on CSR; backward = SDDMM for the
+    Gaussian gradient, pseudo permuted to CSC order, gmmconv on the CSC for the feature
+    gradient, Gaussian backward for pseudo / mu / inv_sigma."""
+
+    @staticmethod
+    def forward(ctx, rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
+        node_feat, pseudo = node_feat.contiguous(), pseudo.contiguous()
+        mu, sigma = mu.contiguous(), sigma.contiguous()
+        out = gmm.gmmconv(rowptr, colind, node_feat, pseudo, mu, sigma)
+        ctx.save_for_backward(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        gaussian_grad = mhsddmm.mhsddmm(rowptr, colind, grad_out, node_feat)
+        pseudo_tran = mhtranspose.mhtranspose(permute, pseudo)
+        node_feat_grad = gmm.gmmconv(colptr, rowind, grad_out, pseudo_tran, mu, sigma)
+        pseudo_out, mu_out, sigma_out = gmm.GaussianBp(pseudo, mu, sigma, gaussian_grad)
+        return None, None, None, None, None, node_feat_grad, pseudo_out, mu_out, sigma_out

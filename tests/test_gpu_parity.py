@@ -1,0 +1,290 @@
+"""GPU parity tests: HIP kernels (through the C ABI, via the drop-in native modules) against
+the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact for index work (CSR<->CSC, permute, arg-max);
+forward outputs and gradients within rel 1e-5 / abs 1e-6 (fp32) of the reference formula.
+The anchor is the oracle's float64 restatement; the oracle's literal float32 restatement of
+the reference kernels is held to the same tolerance in tests/test_oracle.py, so HIP and the
+reference's own arithmetic sit in the same band around the exact value.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import (ATOL, RTOL, assert_close, gat_inputs, named_graphs, rmat_graph)
+
+pytestmark = pytest.mark.gpu
+
+GRAPHS = named_graphs()
+GRAPHS["rmat4k"] = rmat_graph(12, 4000, 60000, 7)      # hubs: rows/columns with 1000+ entries
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def gdev(g):
+    return {k: dev(g[k]) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")}
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import dgnn_amd
+    dgnn_amd.enable_dropin()
+    import fused_gatconv, fused_gmmconv, fused_edgeconv, mhsddmm, mhtranspose, format_conversion
+    from dgnn_amd.native import spmm
+    return dict(gat=fused_gatconv, gmm=fused_gmmconv, edge=fused_edgeconv, sddmm=mhsddmm,
+                tr=mhtranspose, fmt=format_conversion, spmm=spmm)
+
+
+HF_CASES = [(4, 64), (1, 64), (1, 16), (3, 6), (8, 32), (2, 100), (1, 47), (4, 128)]
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+@pytest.mark.parametrize("h,f", HF_CASES)
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_gat_forward_backward(nat, name, h, f, p):
+    g = GRAPHS[name]
+    if name == "rmat4k" and (h, f) not in [(4, 64), (1, 64), (3, 6), (4, 128)]:
+        pytest.skip("large graph: headline shapes only")
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=11)
+    mask = np.random.default_rng(5).random((g["nnz"], h), dtype=np.float32) if p > 0 else None
+    slope = 0.2
+    G = gdev(g)
+    d_in, d_ar, d_ac, d_grad = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    d_mask = dev(mask) if mask is not None else None
+
+    out, emax, esum, emask = nat["gat"].gat_forward(d_ar, d_ac, G["row_ptr"], G["col_ind"], slope,
+                                                    d_in, p, edge_mask=d_mask)
+    o64, m64, s64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope,
+                                           in_feat, p, mask)
+    assert_close(host(out), o64, "out_feat")
+    assert_close(host(esum), s64, "edge_sum")
+    assert_close(host(emax), m64, "edge_max", rtol=1e-6, atol=1e-30)
+    if p == 0.0:
+        assert emask.numel() == 0
+
+    o32, m32, s32 = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope,
+                                       in_feat, p, mask)
+    assert np.array_equal(host(emax), m32), "edge_max must equal the reference's float max exactly"
+
+    gf64, gr64, gc64 = oracle.gat_backward_f64(slope, p, g["row_ptr"], g["col_ind"], mask, in_feat,
+                                               attn_row, attn_col, grad)
+    for with_out in (True, False):
+        gf, gr, gc = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"],
+                                             G["row_ind"], G["permute"], emax, esum, emask, d_in,
+                                             d_ar, d_ac, d_grad, out_feat=out if with_out else None)
+        assert_close(host(gf), gf64, f"grad_feat (out_feat={with_out})")
+        # d = a*(g-S) terms cancel inside these sums: anchor atol on the summand scale (same
+        # allowance the oracle's own float32 restatement needs, tests/test_oracle.py)
+        assert_close(host(gr), gr64, f"grad_attn_row (out_feat={with_out})", atol=2e-6)
+        assert_close(host(gc), gc64, f"grad_attn_col (out_feat={with_out})", atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny", "powerlaw256", "rmat4k"])
+def test_gat_inference_and_tiles(nat, name):
+    g = GRAPHS[name]
+    h, f = 4, 64
+    in_feat, attn_row, attn_col, _ = gat_inputs(g["n"], h, f, seed=3)
+    G = gdev(g)
+    o64, m64, s64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2,
+                                           in_feat, 0.0, None)
+    out = nat["gat"].gat_inference(dev(attn_row), dev(attn_col), G["row_ptr"], G["col_ind"], 0.2,
+                                   dev(in_feat))
+    assert_close(host(out), o64, "inference out")
+    # tile list built as the reference's host scheduler does (script/test/test_gat_tb.py:16-26)
+    deg = np.diff(g["row_ptr"])
+    tiles = [(r, t) for r in range(g["n"]) for t in range((deg[r] + 31) // 32)]
+    ts = dev(np.array(tiles, np.int32).reshape(-1, 2))
+    out2, emax, esum = nat["gat"].gat_forward_tb(dev(attn_row), dev(attn_col), G["row_ptr"],
+                                                 G["col_ind"], 0.2, dev(in_feat), ts)
+    assert_close(host(out2), o64, "tiled out")
+    assert_close(host(esum), s64, "tiled edge_sum")
+
+
+def test_gat_autograd_operator_matches_explicit_backward(nat):
+    from dgnn_amd.operators import GATConvFuse, GATConvFuse_inference
+    g = GRAPHS["powerlaw256"]
+    h, f = 4, 64
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=9)
+    G = gdev(g)
+    x = dev(in_feat).requires_grad_()
+    ar = dev(attn_row).requires_grad_()
+    ac = dev(attn_col).requires_grad_()
+    out = GATConvFuse(ar, ac, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                      0.2, x, 0.0)
+    out.backward(dev(grad))
+    gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, 0.0, g["row_ptr"], g["col_ind"], None, in_feat,
+                                               attn_row, attn_col, grad)
+    assert_close(host(x.grad), gf64, "autograd grad_feat")
+    assert_close(host(ar.grad), gr64, "autograd grad_attn_row", atol=2e-6)
+    assert_close(host(ac.grad), gc64, "autograd grad_attn_col", atol=2e-6)
+    inf = GATConvFuse_inference(ar.detach(), ac.detach(), G["row_ptr"], G["col_ind"], 0.2, x.detach())
+    assert torch.equal(inf, out.detach()), "inference and training forward must agree bit for bit"
+
+
+def test_gat_linearity_and_row_stochasticity_at_scale(nat):
+    """Size-independent properties on a graph too large for the oracle to be the only check:
+    softmax weights sum to one (in_feat = 1 -> out = 1 on non-empty rows) and the operator is
+    linear in in_feat."""
+    g = rmat_graph(17, 100000, 2_000_000, 1)
+    h, f = 4, 64
+    G = gdev(g)
+    rng = np.random.default_rng(0)
+    ar, ac = dev(rng.random((g["n"], h), dtype=np.float32) - 0.6), dev(rng.random((g["n"], h), dtype=np.float32) - 0.4)
+    ones = torch.ones((g["n"], h, f), device=DEV)
+    out = nat["gat"].gat_inference(ar, ac, G["row_ptr"], G["col_ind"], 0.2, ones)
+    nonempty = torch.from_numpy(np.diff(g["row_ptr"]) > 0).to(DEV)
+    assert torch.allclose(out[nonempty], torch.ones_like(out[nonempty]), rtol=0, atol=2e-5)
+    assert torch.all(out[~nonempty] == 0)
+    x = torch.rand((g["n"], h, f), device=DEV) - 0.4
+    y = torch.rand((g["n"], h, f), device=DEV) - 0.4
+    ox = nat["gat"].gat_inference(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x)
+    oy = nat["gat"].gat_inference(ar, ac, G["row_ptr"], G["col_ind"], 0.2, y)
+    oxy = nat["gat"].gat_inference(ar, ac, G["row_ptr"], G["col_ind"], 0.2, 2.0 * x - 3.0 * y)
+    assert torch.allclose(oxy, 2.0 * ox - 3.0 * oy, rtol=1e-5, atol=2e-5)
+    # spot-check 2000 rows against the oracle's float64 formula
+    rows = rng.choice(g["n"], 2000, replace=False)
+    sub_ptr = np.zeros(rows.size + 1, np.int32)
+    cols = []
+    for i, r in enumerate(rows):
+        seg = g["col_ind"][g["row_ptr"][r]:g["row_ptr"][r + 1]]
+        cols.append(seg)
+        sub_ptr[i + 1] = sub_ptr[i] + seg.size
+    sub_col = np.concatenate(cols).astype(np.int32)
+    o64, _, _ = oracle.gat_forward_f64(host(ar)[rows], host(ac), sub_ptr, sub_col, 0.2, host(x), 0.0, None)
+    assert_close(host(ox)[rows], o64, "sampled rows vs oracle", atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny", "er64", "deg_edges", "powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("h,f", [(4, 64), (3, 20), (1, 8), (3, 64)])
+def test_spmm_sddmm_transpose(nat, name, h, f):
+    g = GRAPHS[name]
+    G = gdev(g)
+    rng = np.random.default_rng(1)
+    val = rng.standard_normal((g["nnz"], h)).astype(np.float32)
+    a = rng.standard_normal((g["n"], h, f)).astype(np.float32)
+    b = rng.standard_normal((g["n"], h, f)).astype(np.float32)
+    out = nat["spmm"].spmm_csr(G["row_ptr"], G["col_ind"], dev(val), dev(b))
+    assert_close(host(out), oracle.spmm_csr_f64(g["row_ptr"], g["col_ind"], val, b), "spmm", atol=1e-5)
+    dd = nat["sddmm"].mhsddmm(G["row_ptr"], G["col_ind"], dev(a), dev(b))
+    assert_close(host(dd), oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], a, b), "sddmm", atol=1e-5)
+    tr = nat["tr"].mhtranspose(G["permute"], dev(val))
+    assert np.array_equal(host(tr), oracle.mhtranspose(g["permute"], val)), "mhtranspose must be an exact copy"
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+def test_csr2csc_coo2csr_bit_exact(nat, name):
+    g = GRAPHS[name]
+    G = gdev(g)
+    colptr, rowind, permute = nat["fmt"].csr2csc_int(G["row_ptr"], G["col_ind"])
+    assert np.array_equal(host(colptr), g["col_ptr"])
+    assert np.array_equal(host(rowind), g["row_ind"])
+    assert np.array_equal(host(permute), g["permute"])
+    # reference signature: float data carried along
+    data = dev(np.arange(g["nnz"], dtype=np.float32))
+    cp, ri, cv = nat["fmt"].csr2csc(G["row_ptr"], G["col_ind"], data)
+    assert np.array_equal(host(cv).astype(np.int64), g["permute"].astype(np.int64))
+    coo = np.repeat(np.arange(g["n"]), np.diff(g["row_ptr"])).astype(np.int32)
+    rp = nat["fmt"].coo2csr(dev(coo), g["n"])
+    assert np.array_equal(host(rp), g["row_ptr"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "er64", "powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("k,d,f", [(3, 2, 64), (3, 2, 16), (2, 3, 10), (1, 1, 128)])
+def test_gmm(nat, name, k, d, f):
+    g = GRAPHS[name]
+    G = gdev(g)
+    rng = np.random.default_rng(2)
+    node_feat = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    pseudo = rng.random((g["nnz"], d), dtype=np.float32)
+    mu = (0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    inv_sigma = (1 + 0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    out = nat["gmm"].gmmconv(G["row_ptr"], G["col_ind"], dev(node_feat), dev(pseudo), dev(mu), dev(inv_sigma))
+    assert_close(host(out), oracle.gmmconv_f64(g["row_ptr"], g["col_ind"], node_feat, pseudo, mu, inv_sigma),
+                 "gmm forward", atol=1e-5)
+    ga = nat["gmm"].Gaussian(dev(pseudo), dev(mu), dev(inv_sigma))
+    assert_close(host(ga), oracle.gaussian(pseudo, mu, inv_sigma).astype(np.float64), "gaussian")
+    gg = rng.standard_normal((g["nnz"], k)).astype(np.float32)
+    po, mo, so = nat["gmm"].GaussianBp(dev(pseudo), dev(mu), dev(inv_sigma), dev(gg))
+    po64, mo64, so64 = oracle.gaussian_bp_f64(pseudo, mu, inv_sigma, gg)
+    assert_close(host(po), po64, "pseudo grad", atol=1e-5)
+    # [K,dim] parameter gradients are sums over every edge: scale atol with sqrt(nnz)
+    big = 1e-6 * max(1.0, np.sqrt(g["nnz"]))
+    assert_close(host(mo), mo64, "mu grad", rtol=1e-4, atol=big)
+    assert_close(host(so), so64, "inv_sigma grad", rtol=1e-4, atol=big)
+
+
+def test_gmm_autograd_operator(nat):
+    from dgnn_amd.operators import GmmConvFuse
+    g = GRAPHS["powerlaw256"]
+    G = gdev(g)
+    k, d, f = 3, 2, 16
+    rng = np.random.default_rng(4)
+    node_feat = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    pseudo = rng.random((g["nnz"], d), dtype=np.float32)
+    mu = (0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    inv_sigma = (1 + 0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    go = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    x, ps, m_, sg = (dev(t).requires_grad_() for t in (node_feat, pseudo, mu, inv_sigma))
+    out = GmmConvFuse(G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], x, ps, m_, sg)
+    out.backward(dev(go))
+    # float64 torch autograd of the same formula on the CPU
+    row = torch.from_numpy(np.repeat(np.arange(g["n"]), np.diff(g["row_ptr"]))).long()
+    col = torch.from_numpy(g["col_ind"]).long()
+    X = torch.tensor(node_feat, dtype=torch.float64, requires_grad=True)
+    PS = torch.tensor(pseudo, dtype=torch.float64, requires_grad=True)
+    M = torch.tensor(mu, dtype=torch.float64, requires_grad=True)
+    SG = torch.tensor(inv_sigma, dtype=torch.float64, requires_grad=True)
+    gauss = torch.exp(-0.5 * (((PS[:, None, :] - M[None]) * SG[None]) ** 2).sum(-1))
+    ref = torch.zeros_like(X).index_add(0, row, gauss[:, :, None] * X[col])
+    ref.backward(torch.tensor(go, dtype=torch.float64))
+    assert_close(host(out), ref.detach().numpy(), "gmm out", atol=1e-5)
+    assert_close(host(x.grad), X.grad.numpy(), "gmm grad node_feat", atol=1e-5)
+    assert_close(host(ps.grad), PS.grad.numpy(), "gmm grad pseudo", rtol=1e-4, atol=1e-5)
+    assert_close(host(m_.grad), M.grad.numpy(), "gmm grad mu", rtol=1e-4, atol=1e-4)
+    assert_close(host(sg.grad), SG.grad.numpy(), "gmm grad inv_sigma", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [1, 5, 20, 32, 33, 40, 70])
+@pytest.mark.parametrize("f", [9, 64, 130])
+def test_edgeconv_bit_exact_argmax(nat, k, f):
+    m = 300
+    rng = np.random.default_rng(k * 1000 + f)
+    src = rng.integers(0, m, (m, k)).astype(np.int32)
+    # quantised values force exact ties so the reference's butterfly tie rule is exercised
+    h_src = rng.integers(-2, 3, (m, f)).astype(np.float32)
+    h_dst = rng.integers(-2, 3, (m, f)).astype(np.float32)
+    out, idx_f, idx_i = nat["edge"].edgeconv_forward(k, dev(src.reshape(-1)), dev(h_src), dev(h_dst),
+                                                     return_int_idx=True)
+    ref_out, ref_idx = oracle.edgeconv_forward(k, src.reshape(-1), h_src, h_dst)
+    assert np.array_equal(host(out), ref_out)
+    assert np.array_equal(host(idx_f), ref_idx), "arg-max ids must be bit-exact"
+    assert np.array_equal(host(idx_i), ref_idx.astype(np.int32))
+    go = rng.standard_normal((m, f)).astype(np.float32)
+    gs = nat["edge"].edgeconv_backward(dev(go), idx_i)
+    assert_close(host(gs), oracle.edgeconv_backward_f64(go, ref_idx.astype(np.int32)), "edgeconv bwd", atol=1e-5)
+
+
+def test_edgeconv_continuous_values_and_operator(nat):
+    from dgnn_amd.operators import EdgeConvFuse
+    m, f, k = 2048, 64, 20
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, m, (m, k)).astype(np.int32)
+    h_src = rng.standard_normal((m, f)).astype(np.float32)
+    h_dst = rng.standard_normal((m, f)).astype(np.float32)
+    go = rng.standard_normal((m, f)).astype(np.float32)
+    hs, hd = dev(h_src).requires_grad_(), dev(h_dst).requires_grad_()
+    out = EdgeConvFuse(k, dev(src.reshape(-1)), hs, hd)
+    out.backward(dev(go))
+    ref_out, ref_idx = oracle.edgeconv_forward(k, src.reshape(-1), h_src, h_dst)
+    assert np.array_equal(host(out), ref_out)
+    assert_close(host(hs.grad), oracle.edgeconv_backward_f64(go, ref_idx.astype(np.int32)), "grad_src", atol=1e-5)
+    assert np.array_equal(host(hd.grad), go)
