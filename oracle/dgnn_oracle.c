@@ -467,7 +467,7 @@ static inline float gauss_f32(int dim, const float *ps, const float *mu,
   for (int d = 0; d < dim; ++d) {
     float tmp = ps[d] - mu[d];
     float sig = isg[d];
-    acc += tmp * tmp * sig * sig; /* :42 (no FMA contraction assumed: -ffp-contract=off) */
+    acc = fmaf(tmp * tmp * sig, sig, acc); /* :42, as nvcc contracts `gauss += tmp*tmp*sig*sig` */
   }
   return (float)exp(-0.5 * (double)acc);
 }

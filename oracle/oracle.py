@@ -41,6 +41,7 @@ def _L():
         if not os.path.exists(_SO):
             build()
         _lib = ctypes.CDLL(_SO)
+        _lib.oracle_set_threads(ctypes.c_int(1))   # deterministic by default; bench raises it
     return _lib
 
 

@@ -13,8 +13,8 @@ import scipy.sparse as sp
 import torch
 
 import oracle
-from util import (ATOL, RTOL, assert_close, gat_inputs, named_graphs, random_graph,
-                  tiny_graph)
+from util import (ATOL, RTOL, assert_close, gat_inputs, gat_masses, named_graphs, random_graph,
+                  rmat_graph, tiny_graph)
 
 GRAPHS = named_graphs()
 
@@ -210,3 +210,29 @@ def test_edgeconv_forward_argmax_rule(k):
     np.add.at(ref, (idx.astype(np.int64), np.arange(f)[None, :].repeat(m, 0)), go.astype(np.float64))
     np.testing.assert_allclose(gs, ref, rtol=1e-12, atol=1e-12)
     assert_close(oracle.edgeconv_backward(go, idx.astype(np.int32)), ref, "edgeconv bwd f32", atol=1e-5)
+
+
+def test_reference_arithmetic_needs_mass_term_on_hubs():
+    """On a graph with hub rows/columns (1000+ entries) the literal float32 restatement of the
+    reference kernels itself leaves the plain rel 1e-5 / abs 1e-6 band around the exact value on
+    a few cancelling sums, and sits inside it once 4 ulp of the summand mass are allowed.  The
+    GPU tests use the same (mass-aware) band."""
+    g = rmat_graph(15, 30000, 1_000_000, 3)      # hub rows / columns of several thousand entries
+    h, f = 4, 64
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=11)
+    oracle.set_threads(8)
+    o32, m32, s32 = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0)
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0)
+    gf32, gr32, gc32 = oracle.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                                           g["permute"], m32, s32, None, in_feat, attn_row, attn_col, grad)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, 0.0, g["row_ptr"], g["col_ind"], None, in_feat,
+                                               attn_row, attn_col, grad)
+    oracle.set_threads(1)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2)
+    assert_close(o32, o64, "out", mass=m_out)
+    assert_close(gf32, gf64, "grad_feat", mass=m_gf)
+    assert_close(gr32, gr64, "grad_attn_row", mass=m_gr)
+    assert_close(gc32, gc64, "grad_attn_col", mass=m_gc)
+    strict_bad = sum(int((np.abs(a - b) > ATOL + RTOL * np.abs(b)).sum())
+                     for a, b in ((gf32, gf64), (gr32, gr64), (gc32, gc64)))
+    assert strict_bad > 0, "expected the plain band to be too tight for the reference's own float32 sums"
