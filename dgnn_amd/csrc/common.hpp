@@ -106,6 +106,20 @@ __device__ __forceinline__ float drop_scale(float w, float attn_drop) {
   return (float)((double)w / (1.0 - (double)attn_drop));
 }
 
+// Gaussian mixture weight of one (edge, kernel) pair.
+__device__ __forceinline__ float gmm_weight(int dim, const float *__restrict__ ps,
+                                            const float *__restrict__ mu,
+                                            const float *__restrict__ isg) {
+  // fuseGmm, fused_gmmconv_kernel.cu:38-44: float accumulation, exponent in double
+  float acc = 0.f;
+  for (int d = 0; d < dim; ++d) {
+    const float tmp = ps[d] - mu[d];
+    const float sig = isg[d];
+    acc = fmaf(tmp * tmp * sig, sig, acc);
+  }
+  return (float)exp(-0.5 * (double)acc);
+}
+
 static inline int blocks_for_waves(long long n_waves) {
   return (int)((n_waves + DGNN_WAVES_PER_BLOCK - 1) / DGNN_WAVES_PER_BLOCK);
 }

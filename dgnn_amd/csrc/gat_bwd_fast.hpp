@@ -1,0 +1,292 @@
+// Neighbour-grouped fused GAT backward for gfx950: ONE gather pass over the CSC.
+//
+// The reference backward makes three passes with two per-edge 1 KiB gathers
+// (mhspmm_backward_kernel :712-763 gathers grad rows over the CSC; mhsddmm :814-890 gathers
+// in_feat rows over the CSR with a binary search per edge and writes grad_edge_csr [nnz,h];
+// fused_backward_kernel :892-968 re-gathers attn_col twice and scatters E*H float atomics).
+// Here, for a CSC column c (a source node) every quantity of the edge (r_i -> c) is available
+// while grad[r_i] is in registers:
+//   g_i = <grad[r_i,h,:], in_feat[c,h,:]>           in_feat[c] is the column's OWN row
+//   S_r = sum_j a_j g_j = <grad[r,h,:], out[r,h,:]>  one dense dot per row (k_bwd_rowstat)
+//   d_i = a_i (g_i - S_{r_i}) * (e_i<0 ? slope : 1)
+//   grad_feat[c]     = sum_i w_i grad[r_i]           (w = a * mask/(1-p))
+//   grad_attn_col[c] = sum_i d_i                     plain sum, no atomics
+//   dE[permute[i]]   = d_i                           16-byte scatter, summed per row afterwards
+// so the second 1 KiB gather, the [nnz,h] grad_edge_csr round trip, the binary searches and
+// all float atomics disappear.
+//
+// Work decomposition: fixed neighbour groups of L CSC entries per wave64 (see gather_fast.hpp).
+// The column's own in_feat row travels through the SAME software-pipelined load stream as the
+// gathered grad rows (a "U item" in front of the column's edges), so a switch of column never
+// stalls the pipeline.
+#pragma once
+#include "common.hpp"
+#include "gather_fast.hpp"
+
+namespace dgnn {
+
+#define DGNN_BWD_UFLAG 0x80000000u   // stream item = the column's own in_feat row
+#define DGNN_BWD_END 0x40000000u     // stream item = last edge of its column inside the group
+#define DGNN_BWD_IDMASK 0x3fffffffu
+
+struct BwdParams {
+  int n, m, nnz, H, F, HF, L, T;
+  int rowv;            // HF/4 float4 slots per feature row (<= 64)
+  int fv;              // F/4 lanes per head (power of two)
+  int slot_stride;     // HF + H rounded up to 4
+  float attn_drop, slope;
+  const int *col_ptr, *row_ind, *permute;
+  const float *attn_row, *attn_col, *edge_max, *edge_sum, *edge_mask;
+  const float *in_feat, *grad, *out_feat;
+  const float *S_in;   // optional precomputed row dots [m,H]
+  float4 *rowstat;     // [m][H] {attn_row, edge_max, edge_sum, S}
+  float *dE;           // [nnz][H] in CSR order
+  float *grad_feat, *grad_attn_col;
+  int *task_col0;
+  float *slots;        // [2T][slot_stride]
+};
+
+static inline int bwd_group_size(int H) { return H <= 4 ? 128 : 64; }
+static inline size_t bwd_lds_bytes(int H, int L) {
+  // per wave: raw float4 [L][H] + ridl[L] + kof[L] + colk[L] + dq[L] + stream[2L]
+  return (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)L * H * 16 + (size_t)L * 6 * 4);
+}
+
+// Per destination row: S[r,h] = <grad[r,h,:], out[r,h,:]> and the packed statistics the CSC pass
+// gathers with one 16-byte load per (edge, head).  One wave per row, float4 per lane.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= P.m) return;
+  const int lane = lane_id();
+  const bool active = lane < P.rowv;
+  const int head = active ? (lane * 4) / P.F : 0;
+  float s = 0.f;
+  if (P.S_in == nullptr) {
+    if (active) {
+      const float4 g = *(const float4 *)(P.grad + (size_t)r * P.HF + (size_t)lane * 4);
+      const float4 o = *(const float4 *)(P.out_feat + (size_t)r * P.HF + (size_t)lane * 4);
+      s = fmaf(g.x, o.x, fmaf(g.y, o.y, fmaf(g.z, o.z, g.w * o.w)));
+    }
+    s = group_reduce(s, P.fv, OpSum());
+  } else if (active) {
+    s = P.S_in[(size_t)r * P.H + head];
+  }
+  if (active && (lane % P.fv) == 0) {
+    const size_t i = (size_t)r * P.H + head;
+    P.rowstat[i] = make_float4(P.attn_row[i], P.edge_max[i], P.edge_sum[i], s);
+  }
+}
+
+// Column bookkeeping: empty columns are finished here, every group learns its first column.
+__global__ void k_bwd_prep_cols(BwdParams P) {
+  for (long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x; c < P.n;
+       c += (long long)gridDim.x * blockDim.x) {
+    const int lb = P.col_ptr[c], hb = P.col_ptr[c + 1];
+    if (lb == hb) {
+      float *o = P.grad_feat + (size_t)c * P.HF;
+      for (int i = 0; i < P.HF; ++i) o[i] = 0.f;
+      for (int h = 0; h < P.H; ++h) P.grad_attn_col[(size_t)c * P.H + h] = 0.f;
+    } else {
+      for (int t = (lb + P.L - 1) / P.L; t <= (hb - 1) / P.L; ++t) P.task_col0[t] = (int)c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
+  extern __shared__ __align__(16) float lds_raw[];
+  const int wib = wave_in_block();
+  const int lane = lane_id();
+  const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
+  if (t >= P.T) return;
+  const int L = P.L, H = P.H;
+  const size_t per_wave_floats = (size_t)L * H * 4 + (size_t)L * 6;
+  float4 *raw = (float4 *)(lds_raw + (size_t)wib * per_wave_floats);   // [L][H]
+  int *ridl = (int *)(raw + (size_t)L * H);                            // [L] row id of edge p
+  unsigned *kof = (unsigned *)(ridl + L);                              // [L] column ordinal | END
+  int *colk = (int *)(kof + L);                                        // [L] column id of ordinal k
+  int *dq = colk + L;                                                  // [L] flush destination of ordinal k
+  unsigned *stream = (unsigned *)(dq + L);                             // [2L] load stream
+
+  const int e0 = t * L;
+  const int e1 = min(e0 + L, P.nnz);
+  const int cnt = e1 - e0;
+
+  // ---------------------------------------------------------------- phase A: stage row data
+  for (int p = lane; p < cnt; p += DGNN_WAVE) {
+    const int rid = P.row_ind[e0 + p];
+    ridl[p] = rid;
+    for (int h = 0; h < H; ++h) raw[(size_t)p * H + h] = P.rowstat[(size_t)rid * H + h];
+  }
+
+  // ---------------------------------------------------------------- columns of the group
+  int K = 0;   // non-empty columns seen so far
+  {
+    int cbase = uniform_i32(P.task_col0[t]);
+    while (true) {
+      const int c = cbase + lane;
+      int lo = 0x7fffffff, hi = 0x7fffffff;
+      if (c < P.n) {
+        lo = P.col_ptr[c];
+        hi = P.col_ptr[c + 1];
+      }
+      const int a = max(lo, e0) - e0;
+      const int b = (hi < e1 ? hi : e1) - e0;
+      const bool nonempty = (c < P.n) && (lo < e1) && (b > a);
+      const unsigned long long bal = __ballot(nonempty);
+      const int k = K + __popcll(bal & ((1ull << lane) - 1ull));
+      if (nonempty) {
+        const bool whole = (lo >= e0) && (hi <= e1);
+        const int slot = (lo < e0) ? 2 * t : 2 * t + 1;
+        colk[k] = c;
+        dq[k] = whole ? c : -(slot + 1);
+        stream[a + k] = (unsigned)c | DGNN_BWD_UFLAG;
+        for (int p = a; p < b; ++p) kof[p] = (unsigned)k | (p == b - 1 ? DGNN_BWD_END : 0u);
+      }
+      K += __popcll(bal);
+      const bool reached_end = (c >= P.n - 1) || (hi >= e1);
+      if (__ballot(reached_end) != 0ull) break;
+      cbase += DGNN_WAVE;
+    }
+  }
+  wave_lds_sync();
+
+  // ---------------------------------------------------------------- per-edge coefficients
+  for (int p = lane; p < cnt; p += DGNN_WAVE) {
+    const unsigned kk = kof[p];
+    const int k = (int)(kk & DGNN_BWD_IDMASK);
+    const int c = colk[k];
+    stream[p + k + 1] = (unsigned)ridl[p] | (kk & DGNN_BWD_END);
+    const int pos = (P.edge_mask != nullptr) ? P.permute[e0 + p] : 0;
+    for (int h = 0; h < H; ++h) {
+      const float4 st = raw[(size_t)p * H + h];              // {attn_row, edge_max, edge_sum, S}
+      const float e = leaky_relu(st.x + P.attn_col[(size_t)c * H + h], P.slope);
+      const float a = expf(e - st.y) / st.z;                 // :747
+      float w = a;
+      if (P.edge_mask != nullptr) {
+        if (!(P.edge_mask[(size_t)pos * H + h] > P.attn_drop)) w = 0.f;   // :738
+        w = w / (1 - P.attn_drop);                                        // :749 (float divide)
+      }
+      const bool neg = e < 0.f;                                           // :953
+      const float B = a * st.w * (neg ? P.slope : 1.f);
+      raw[(size_t)p * H + h] = make_float4(neg ? -w : w, B, 0.f, 0.f);
+    }
+  }
+  wave_lds_sync();
+
+  // ---------------------------------------------------------------- pipelined gather stream
+  const bool active = lane < P.rowv;
+  const int head = active ? (lane * 4) / P.F : 0;
+  const size_t lane_off = (size_t)(active ? lane : 0) * 4;
+  const bool head_leader = active && (lane % P.fv) == 0;
+  const int items = cnt + K;
+  float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dsum = 0.f;
+  int k = -1;
+  float4 ring[DGNN_FAST_U];
+#pragma unroll
+  for (int i = 0; i < DGNN_FAST_U; ++i) {
+    ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < items) {
+      const unsigned v = (unsigned)uniform_i32((int)stream[i]);
+      const float *base = (v & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
+      if (active) ring[i] = *(const float4 *)(base + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off);
+    }
+  }
+  for (int j = 0; j < items; j += DGNN_FAST_U) {
+#pragma unroll
+    for (int i = 0; i < DGNN_FAST_U; ++i) {
+      const int it = j + i;
+      if (it < items) {
+        const float4 x = ring[i];
+        const unsigned v = (unsigned)uniform_i32((int)stream[it]);
+        if (it + DGNN_FAST_U < items) {
+          const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
+          const float *base = (nv & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
+          if (active) ring[i] = *(const float4 *)(base + (size_t)(nv & DGNN_BWD_IDMASK) * P.HF + lane_off);
+        }
+        if (v & DGNN_BWD_UFLAG) {
+          u = x;
+          ++k;
+        } else {
+          const int p = it - (k + 1);
+          float4 *cell = raw + (size_t)p * H + head;
+          const float2 wb = *(const float2 *)cell;
+          const float w = fabsf(wb.x);
+          const float sl = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
+          float dot = fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
+          dot = group_reduce(dot, P.fv, OpSum());
+          const float d = fmaf(sl * w, dot, -wb.y);
+          acc.x = fmaf(w, x.x, acc.x);
+          acc.y = fmaf(w, x.y, acc.y);
+          acc.z = fmaf(w, x.z, acc.z);
+          acc.w = fmaf(w, x.w, acc.w);
+          dsum += d;
+          if (head_leader) ((float *)cell)[2] = d;
+          if (v & DGNN_BWD_END) {
+            const int dst = uniform_i32(dq[k]);
+            if (dst >= 0) {
+              if (active) *(float4 *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
+              if (head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
+            } else {
+              float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
+              if (active) *(float4 *)(sp + lane_off) = acc;
+              if (head_leader) sp[P.HF + head] = dsum;
+            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            dsum = 0.f;
+          }
+        }
+      }
+    }
+  }
+  wave_lds_sync();
+
+  // ---------------------------------------------------------------- d_i to CSR order
+  for (int p = lane; p < cnt; p += DGNN_WAVE) {
+    const size_t pos = (size_t)P.permute[e0 + p];
+    if (H == 4) {
+      const float4 d4 = make_float4(((const float *)&raw[(size_t)p * 4 + 0])[2],
+                                    ((const float *)&raw[(size_t)p * 4 + 1])[2],
+                                    ((const float *)&raw[(size_t)p * 4 + 2])[2],
+                                    ((const float *)&raw[(size_t)p * 4 + 3])[2]);
+      *(float4 *)(P.dE + pos * 4) = d4;
+    } else {
+      for (int h = 0; h < H; ++h) P.dE[pos * H + h] = ((const float *)&raw[(size_t)p * H + h])[2];
+    }
+  }
+}
+
+// Merge the partial slots of columns cut by a group boundary (plain sums, fixed order).
+__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
+  const int lane = lane_id();
+  const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) + 1;
+  if (t >= P.T) return;
+  const int L = P.L, H = P.H;
+  const int c = uniform_i32(P.task_col0[t]);
+  const int cs = uniform_i32(P.col_ptr[c]), ce = uniform_i32(P.col_ptr[c + 1]);
+  const long long edge = (long long)t * L;
+  if (cs >= edge) return;
+  if (cs < edge - L) return;
+  const int t_last = (ce - 1) / L;
+  const int npieces = t_last - t + 2;
+  const bool active = lane < P.rowv;
+  const int head = active ? (lane * 4) / P.F : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dsum = 0.f;
+  for (int i = 0; i < npieces; ++i) {
+    const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
+    const float *sp = P.slots + (size_t)s * P.slot_stride;
+    if (active) {
+      const float4 v = *(const float4 *)(sp + (size_t)lane * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      dsum += sp[P.HF + head];
+    }
+  }
+  if (active) {
+    *(float4 *)(P.grad_feat + (size_t)c * P.HF + (size_t)lane * 4) = acc;
+    if ((lane % P.fv) == 0) P.grad_attn_col[(size_t)c * H + head] = dsum;
+  }
+}
+
+}  // namespace dgnn

@@ -3,6 +3,7 @@
 // gat_fast.hpp and is used whenever its layout constraints hold (see gat.hip).
 #pragma once
 #include "common.hpp"
+#include "gather_fast.hpp"
 
 namespace dgnn {
 
@@ -221,5 +222,51 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,
     }
   }
 }
+
+// --------------------------------------------------------------------------- SpMM / GMM
+// One wave per CSR row.  WEIGHT = 0: caller-supplied edge values (GE-SpMM, phase 3 of
+// fused_gatconv_kernel.cu:87-117).  WEIGHT = 1: Gaussian kernel weight computed on the fly
+// from pseudo coordinates (fuseGmm, fused_gmmconv_kernel.cu:24-55): float accumulation of
+// ((p-mu)^2 * sig^2), exponent in DOUBLE as the reference's `exp(-0.5 * gauss)` (:44).
+template <int WEIGHT>
+__global__ __launch_bounds__(DGNN_BLOCK) void k_spmm_row(
+    int m, int H, int F, int dim, const int *__restrict__ row_ptr,
+    const int *__restrict__ col_ind, const float *__restrict__ edge_val,
+    const float *__restrict__ pseudo, const float *__restrict__ mu,
+    const float *__restrict__ inv_sigma, const float *__restrict__ in_feat,
+    float *__restrict__ out) {
+  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+  if (r >= m) return;
+  const int lane = lane_id();
+  const int lb = row_ptr[r], hb = row_ptr[r + 1];
+  const size_t HF = (size_t)H * F;
+  for (int h = 0; h < H; ++h) {
+    for (int fb = 0; fb < F; fb += DGNN_WAVE) {
+      const int fid = fb + lane;
+      float acc = 0.f;
+      for (int base = lb; base < hb; base += DGNN_WAVE) {
+        const int p = base + lane;
+        float w = 0.f;
+        int c = 0;
+        if (p < hb) {
+          c = col_ind[p];
+          if (WEIGHT == 0)
+            w = edge_val[(size_t)p * H + h];
+          else
+            w = gmm_weight(dim, pseudo + (size_t)p * dim, mu + (size_t)h * dim,
+                             inv_sigma + (size_t)h * dim);
+        }
+        const int n = min(DGNN_WAVE, hb - base);
+        for (int k = 0; k < n; ++k) {
+          const int ck = bcast_i32(c, k);
+          const float wk = bcast_f32(w, k);
+          if (fid < F) acc = fmaf(wk, in_feat[(size_t)ck * HF + (size_t)h * F + fid], acc);
+        }
+      }
+      if (fid < F) out[(size_t)r * HF + (size_t)h * F + fid] = acc;
+    }
+  }
+}
+
 
 }  // namespace dgnn

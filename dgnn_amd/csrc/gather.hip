@@ -1,0 +1,368 @@
+// C-ABI entry points of the row-gather family (include/dgnn_hip.h): fused GAT forward /
+// inference / backward, GE-SpMM and fused GMMConv forward, plus kernel selection between the
+// neighbour-grouped fast path (gather_fast.hpp, gat_bwd_fast.hpp) and the shape-agnostic
+// wave-per-row path (gat_generic.hpp).
+#include <cstdlib>
+
+#include "gat_bwd_fast.hpp"
+#include "gat_generic.hpp"
+#include "gather_fast.hpp"
+
+using namespace dgnn;
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// DGNN_FORCE_GENERIC=1 routes everything through the wave-per-row kernels (A/B testing).
+inline bool force_generic() {
+  const char *e = std::getenv("DGNN_FORCE_GENERIC");
+  return e != nullptr && e[0] == '1';
+}
+
+// ----------------------------------------------------------------------------- forward side
+struct FwdLayout {
+  int L, T, slot_stride;
+  size_t off_rows, off_slots, total;
+};
+
+FwdLayout fwd_layout(int nnz, int h, int f) {
+  FwdLayout w;
+  w.L = fast_group_size(h);
+  w.T = (nnz + w.L - 1) / w.L;
+  w.slot_stride = (int)align_up((size_t)h * f + 2 * (size_t)h, 4);
+  size_t o = 0;
+  w.off_rows = o;
+  o += align_up(sizeof(int) * (size_t)(w.T > 0 ? w.T : 1), 256);
+  w.off_slots = o;
+  o += align_up(sizeof(float) * 2 * (size_t)w.T * w.slot_stride, 256);
+  w.total = o;
+  return w;
+}
+
+bool fwd_fast_ok(int m, int h) { return h <= DGNN_FAST_HMAX && m < (1 << 30) && !force_generic(); }
+
+template <int MODE>
+int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, hipStream_t st) {
+  const FwdLayout w = fwd_layout(P.nnz, P.H, P.F);
+  if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
+  P.HF = P.H * P.F;
+  P.L = w.L;
+  P.T = w.T;
+  P.slot_stride = w.slot_stride;
+  P.task_row0 = (int *)((char *)workspace + w.off_rows);
+  P.slots = (float *)((char *)workspace + w.off_slots);
+  const bool vec4 = (P.F % 4 == 0) && aligned16(P.in_feat) && aligned16(P.out);
+  const bool attn_ok = (MODE != MODE_GAT) || P.H != 4 || aligned16(P.attn_col);
+  if (!attn_ok) return DGNN_ERR_ALIGNMENT;
+  P.rowv = vec4 ? P.HF / 4 : P.HF;
+  {
+    long long g = ((long long)P.m + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_fast_prep_rows, dim3((unsigned)g), dim3(256), 0, st, P);
+    DGNN_LAUNCH_CHECK();
+  }
+  if (P.T == 0) return DGNN_OK;
+  const size_t lds = fast_lds_bytes(P.H, P.L);
+  const dim3 grid(blocks_for_waves(P.T));
+  if (vec4)
+    hipLaunchKernelGGL((k_fast_row_gather<MODE, 4>), grid, dim3(DGNN_BLOCK), lds, st, P);
+  else
+    hipLaunchKernelGGL((k_fast_row_gather<MODE, 1>), grid, dim3(DGNN_BLOCK), lds, st, P);
+  DGNN_LAUNCH_CHECK();
+  if (P.T > 1) {
+    hipLaunchKernelGGL(k_fast_fixup<MODE>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+    DGNN_LAUNCH_CHECK();
+  }
+  return DGNN_OK;
+}
+
+int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
+                   const float *attn_row, const float *attn_col, const int *row_ptr,
+                   const int *col_ind, const float *in_feat, const float *edge_mask,
+                   float *edge_max, float *edge_sum, float *out_feat, void *workspace,
+                   size_t workspace_bytes, hipStream_t st) {
+  if (m == 0) return DGNN_OK;
+  if (fwd_fast_ok(m, h) && !(h == 4 && !aligned16(attn_col))) {
+    GatherParams P = {};
+    P.m = m; P.nnz = nnz; P.H = h; P.F = f;
+    P.attn_drop = attn_drop; P.slope = slope;
+    P.row_ptr = row_ptr; P.col_ind = col_ind;
+    P.attn_row = attn_row; P.attn_col = attn_col; P.edge_mask = edge_mask;
+    P.in_feat = in_feat; P.edge_max = edge_max; P.edge_sum = edge_sum; P.out = out_feat;
+    return launch_fast_gather<MODE_GAT>(P, workspace, workspace_bytes, st);
+  }
+  hipLaunchKernelGGL(k_gat_fwd_row, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, m, h, f,
+                     attn_drop, slope, attn_row, attn_col, row_ptr, col_ind, in_feat, edge_mask,
+                     edge_max, edge_sum, out_feat);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+// ----------------------------------------------------------------------------- backward side
+struct BwdLayout {
+  bool fast;
+  int L, T, slot_stride;
+  size_t off_S, off_dE, off_stat, off_cols, off_slots, off_out, off_fwd, total;
+};
+
+bool bwd_fast_shape(int m, int n, int h, int f) {
+  return !force_generic() && h <= DGNN_FAST_HMAX && (f % 4 == 0) && (h * f <= 256) &&
+         is_pow2(f / 4) && m < (1 << 30) && n < (1 << 30);
+}
+
+BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
+  BwdLayout w = {};
+  w.fast = bwd_fast_shape(m, n, h, f);
+  size_t o = 0;
+  w.off_S = o;
+  o += align_up(sizeof(float) * (size_t)m * h, 256);
+  w.off_dE = o;
+  o += align_up(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1) * h, 256);
+  if (w.fast) {
+    w.L = bwd_group_size(h);
+    w.T = (nnz + w.L - 1) / w.L;
+    w.slot_stride = (int)align_up((size_t)h * f + (size_t)h, 4);
+    w.off_stat = o;
+    o += align_up(sizeof(float4) * (size_t)m * h, 256);
+    w.off_cols = o;
+    o += align_up(sizeof(int) * (size_t)(w.T > 0 ? w.T : 1), 256);
+    w.off_slots = o;
+    o += align_up(sizeof(float) * 2 * (size_t)w.T * w.slot_stride, 256);
+  }
+  w.off_out = o;
+  if (need_recompute) o += align_up(sizeof(float) * (size_t)m * h * f, 256);
+  w.off_fwd = o;
+  if (need_recompute) o += align_up(fwd_layout(nnz, h, f).total, 256);
+  w.total = o;
+  return w;
+}
+
+int check_dims(int m, int nnz, int h, int f) {
+  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if ((long long)h * f > (1 << 20)) return DGNN_ERR_UNSUPPORTED;
+  return DGNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dgnn_gat_forward_workspace_bytes(int m, int nnz, int h, int f) {
+  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
+  return fwd_layout(nnz, h, f).total;
+}
+
+int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                     const float *attn_row, const float *attn_col, const int *row_ptr,
+                     const int *col_ind, const float *in_feat, const float *edge_mask,
+                     float *edge_max, float *edge_sum, float *out_feat, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (!attn_row || !attn_col || !row_ptr || !in_feat || !out_feat || !edge_max || !edge_sum)
+    return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && !col_ind) return DGNN_ERR_BAD_ARG;
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
+  if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+    return DGNN_ERR_WORKSPACE;
+  return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
+                        col_ind, in_feat, attn_drop > 0.f ? edge_mask : nullptr, edge_max, edge_sum,
+                        out_feat, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope, const float *attn_row,
+                       const float *attn_col, const int *row_ptr, const int *col_ind,
+                       const float *in_feat, float *out_feat, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (!attn_row || !attn_col || !row_ptr || !in_feat || !out_feat) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && !col_ind) return DGNN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+    return DGNN_ERR_WORKSPACE;
+  return launch_forward(m, nnz, h, f, 0.f, negative_slope, attn_row, attn_col, row_ptr, col_ind,
+                        in_feat, nullptr, nullptr, nullptr, out_feat, workspace, workspace_bytes,
+                        (hipStream_t)stream);
+}
+
+int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
+                           const float *attn_row, const float *attn_col, const int *row_ptr,
+                           const int *col_ind, const float *in_feat, const int *tile_scheduler,
+                           int n_tiles, float *edge_max, float *edge_sum, float *out_feat,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+  if (n_tiles < 0 || (n_tiles > 0 && !tile_scheduler)) return DGNN_ERR_BAD_ARG;
+  return dgnn_gat_forward(m, nnz, h, f, 0.f, negative_slope, attn_row, attn_col, row_ptr, col_ind,
+                          in_feat, nullptr, edge_max, edge_sum, out_feat, workspace,
+                          workspace_bytes, stream);
+}
+
+int dgnn_gat_row_dot(int m, int h, int f, const float *grad, const float *out_feat,
+                     float *row_dot, void *stream) {
+  if (m < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (!grad || !out_feat || !row_dot) return DGNN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_gat_row_dot, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, m, h, f, grad, out_feat, row_dot);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+size_t dgnn_gat_backward_workspace_bytes(int m, int n, int nnz, int h, int f, int have_row_term) {
+  if (m < 0 || n < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
+  return bwd_layout(m, n, nnz, h, f, !have_row_term).total;
+}
+
+int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
+                      const int *row_ptr, const int *col_ind, const int *col_ptr,
+                      const int *row_ind, const int *permute, const float *edge_max,
+                      const float *edge_sum, const float *edge_mask, const float *in_feat,
+                      const float *attn_row, const float *attn_col, const float *grad,
+                      const float *out_feat, const float *row_dot, float *grad_feat,
+                      float *grad_attn_row, float *grad_attn_col, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (n < 0) return DGNN_ERR_BAD_ARG;
+  if (!row_ptr || !col_ptr || !grad_attn_row) return DGNN_ERR_BAD_ARG;
+  if (m > 0 && (!edge_max || !edge_sum || !attn_row || !grad)) return DGNN_ERR_BAD_ARG;
+  if (n > 0 && (!in_feat || !attn_col || !grad_feat || !grad_attn_col)) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!col_ind || !row_ind || !permute)) return DGNN_ERR_BAD_ARG;
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
+  if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
+  const bool have_row_term = (out_feat != nullptr) || (row_dot != nullptr);
+  BwdLayout w = bwd_layout(m, n, nnz, h, f, !have_row_term);
+  if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float *mask = attn_drop > 0.f ? edge_mask : nullptr;
+  char *ws = (char *)workspace;
+  float *S = (float *)(ws + w.off_S);
+  float *dE = (float *)(ws + w.off_dE);
+  const float *out = out_feat;
+  if (!have_row_term && m > 0) {
+    // Reference-signature path: the saved forward output was not handed over, rebuild it.
+    float *tmp = (float *)(ws + w.off_out);
+    rc = launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
+                        col_ind, in_feat, mask, nullptr, nullptr, tmp, ws + w.off_fwd,
+                        w.total - w.off_fwd, st);
+    if (rc) return rc;
+    out = tmp;
+  }
+  bool fast = w.fast && aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
+              (out == nullptr || aligned16(out));
+  if (fast) {
+    BwdParams P = {};
+    P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
+    P.L = w.L; P.T = w.T; P.rowv = h * f / 4; P.fv = f / 4; P.slot_stride = w.slot_stride;
+    P.attn_drop = attn_drop; P.slope = negative_slope;
+    P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
+    P.attn_row = attn_row; P.attn_col = attn_col; P.edge_max = edge_max; P.edge_sum = edge_sum;
+    P.edge_mask = mask; P.in_feat = in_feat; P.grad = grad; P.out_feat = out;
+    P.S_in = row_dot;
+    P.rowstat = (float4 *)(ws + w.off_stat);
+    P.dE = dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
+    P.task_col0 = (int *)(ws + w.off_cols);
+    P.slots = (float *)(ws + w.off_slots);
+    if (m > 0) {
+      hipLaunchKernelGGL(k_bwd_rowstat, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
+      DGNN_LAUNCH_CHECK();
+    }
+    if (n > 0) {
+      long long g = ((long long)n + 255) / 256;
+      if (g > 8192) g = 8192;
+      hipLaunchKernelGGL(k_bwd_prep_cols, dim3((unsigned)g), dim3(256), 0, st, P);
+      DGNN_LAUNCH_CHECK();
+    }
+    if (P.T > 0) {
+      hipLaunchKernelGGL(k_bwd_col_gather, dim3(blocks_for_waves(P.T)), dim3(DGNN_BLOCK),
+                         bwd_lds_bytes(h, P.L), st, P);
+      DGNN_LAUNCH_CHECK();
+      if (P.T > 1) {
+        hipLaunchKernelGGL(k_bwd_fixup, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+        DGNN_LAUNCH_CHECK();
+      }
+    }
+  } else {
+    const float *Sp = row_dot;
+    if (!Sp && m > 0) {
+      hipLaunchKernelGGL(k_gat_row_dot, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, m, h, f,
+                         grad, out, S);
+      DGNN_LAUNCH_CHECK();
+      Sp = S;
+    }
+    if (n > 0) {
+      hipLaunchKernelGGL(k_gat_bwd_col, dim3(blocks_for_waves(n)), dim3(DGNN_BLOCK), 0, st, n, h, f,
+                         negative_slope, attn_drop, col_ptr, row_ind, permute, edge_max, edge_sum,
+                         mask, attn_row, attn_col, in_feat, grad, Sp, dE, grad_feat, grad_attn_col);
+      DGNN_LAUNCH_CHECK();
+    }
+  }
+  if (m > 0) {
+    hipLaunchKernelGGL(k_gat_row_sum, dim3((m + 15) / 16), dim3(DGNN_BLOCK), 0, st, m, h, row_ptr,
+                       dE, grad_attn_row);
+    DGNN_LAUNCH_CHECK();
+  }
+  return DGNN_OK;
+}
+
+// ------------------------------------------------------------------------- GE-SpMM / GMM
+size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f) {
+  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
+  return fwd_layout(nnz, h, f).total;
+}
+
+int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                  const float *edge_val, const float *in_feat, float *out_feat, void *workspace,
+                  size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (!row_ptr || !in_feat || !out_feat || (nnz > 0 && (!col_ind || !edge_val))) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (fwd_fast_ok(m, h)) {
+    GatherParams P = {};
+    P.m = m; P.nnz = nnz; P.H = h; P.F = f;
+    P.row_ptr = row_ptr; P.col_ind = col_ind; P.edge_val = edge_val;
+    P.in_feat = in_feat; P.out = out_feat;
+    return launch_fast_gather<MODE_VAL>(P, workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  hipLaunchKernelGGL(k_spmm_row<0>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, m, h, f, 0, row_ptr, col_ind, edge_val,
+                     (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, in_feat,
+                     out_feat);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+size_t dgnn_gmm_forward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
+  if (nodes < 0 || nnz < 0 || kernels <= 0 || embed <= 0) return 0;
+  return fwd_layout(nnz, kernels, embed).total;
+}
+
+int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
+                     const int *col_ind, const float *node_feat, const float *pseudo,
+                     const float *mu, const float *inv_sigma, float *out, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  int rc = check_dims(nodes, nnz, kernels, embed);
+  if (rc) return rc;
+  if (dim <= 0) return DGNN_ERR_BAD_ARG;
+  if (!csr_ptr || !node_feat || !mu || !inv_sigma || !out || (nnz > 0 && (!col_ind || !pseudo)))
+    return DGNN_ERR_BAD_ARG;
+  if (nodes == 0) return DGNN_OK;
+  if (fwd_fast_ok(nodes, kernels)) {
+    GatherParams P = {};
+    P.m = nodes; P.nnz = nnz; P.H = kernels; P.F = embed; P.dim = dim;
+    P.row_ptr = csr_ptr; P.col_ind = col_ind; P.pseudo = pseudo; P.mu = mu; P.inv_sigma = inv_sigma;
+    P.in_feat = node_feat; P.out = out;
+    return launch_fast_gather<MODE_GMM>(P, workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  hipLaunchKernelGGL(k_spmm_row<1>, dim3(blocks_for_waves(nodes)), dim3(DGNN_BLOCK), 0,
+                     (hipStream_t)stream, nodes, kernels, embed, dim, csr_ptr, col_ind,
+                     (const float *)nullptr, pseudo, mu, inv_sigma, node_feat, out);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// Neighbour-grouped row-gather engine for gfx950 (wave64): the fast path of the fused GAT
+// forward, GE-SpMM and fused GMMConv forward.
+//
+// Work decomposition (what replaces the reference's one-block-per-(row,head) launch,
+// fused_gatconv_kernel.cu:344, and its experimental tile scheduler, :1153-1237):
+//   * the nnz array is cut into fixed NEIGHBOUR GROUPS of L consecutive edges; one wave64
+//     owns one group, whatever rows it spans.  Short rows are packed many-per-wave, a hub
+//     row of 100k neighbours is spread over hundreds of waves: every wave gathers the same
+//     number of feature rows, so there is no tail and no host-side scheduler.
+//   * phase A  the wave stages its L column ids and their per-head score terms in LDS
+//              (one coalesced index load + one 16-byte gather per edge, once).
+//   * phase B  per row segment inside the group: LeakyReLU scores, max / sum reductions with
+//              DPP row ops, softmax weights written back to LDS in place.  A row that lies
+//              wholly inside the group is finished here exactly like the reference
+//              (w = exp(e-max)/sum per edge); a row cut by a group boundary keeps
+//              un-normalised exp(e-m_piece) and leaves (m, s, acc) in a partial slot.
+//   * phase C  ONE flat, software-pipelined stream over the group's edges: U feature-row
+//              gathers always in flight per wave (each a fully coalesced 16 B/lane load:
+//              64 lanes x float4 = one 1 KiB [H=4,F=64] row), accumulate, and flush at row
+//              ends (flag bit in the staged column id).  No atomics anywhere.
+//   * a tiny fix-up kernel merges the partial slots of cut rows in a fixed order (online
+//              softmax merge), so results are deterministic.
+#pragma once
+#include "common.hpp"
+
+namespace dgnn {
+
+#define DGNN_FAST_U 8          // feature-row gathers in flight per wave
+#define DGNN_FAST_HMAX 8
+#define DGNN_ROWEND 0x80000000u
+
+enum { MODE_GAT = 0, MODE_VAL = 1, MODE_GMM = 2 };
+
+struct GatherParams {
+  int m, nnz, H, F, HF, L, T;        // rows, edges, heads, feat, H*F, group size, #groups
+  int rowv;                          // HF / VEC : vector slots per feature row
+  int slot_stride;                   // floats per partial slot (HF + 2H rounded up to 4)
+  int dim;                           // GMM pseudo dimension
+  float attn_drop, slope;
+  const int *row_ptr, *col_ind;
+  const float *attn_row, *attn_col;  // GAT
+  const float *edge_mask;            // GAT dropout mask or NULL
+  const float *edge_val;             // SpMM values [nnz,H]
+  const float *pseudo, *mu, *inv_sigma;  // GMM
+  const float *in_feat;
+  float *edge_max, *edge_sum;        // GAT stats or NULL
+  float *out;
+  int *task_row0;                    // [T] row that contains edge t*L
+  float *slots;                      // [2T][slot_stride]
+};
+
+static inline int fast_group_size(int H) { return H <= 4 ? 256 : 128; }
+static inline size_t fast_lds_bytes(int H, int L) {
+  // per wave: weights [L*H] + column ids [L] + flush queue [L]
+  return (size_t)DGNN_WAVES_PER_BLOCK * (size_t)L * (H + 2) * sizeof(float);
+}
+
+// Row bookkeeping: empty rows are finished here (out = 0, edge_max = -1e38, edge_sum = 0:
+// fused_gatconv_kernel.cu:45,66,90) and every group learns the row its first edge belongs to.
+__global__ void k_fast_prep_rows(GatherParams P) {
+  for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < P.m;
+       r += (long long)gridDim.x * blockDim.x) {
+    const int lb = P.row_ptr[r], hb = P.row_ptr[r + 1];
+    if (lb == hb) {
+      float *o = P.out + (size_t)r * P.HF;
+      for (int i = 0; i < P.HF; ++i) o[i] = 0.f;
+      if (P.edge_max != nullptr)
+        for (int h = 0; h < P.H; ++h) {
+          P.edge_max[(size_t)r * P.H + h] = DGNN_NEG_INIT;
+          P.edge_sum[(size_t)r * P.H + h] = 0.f;
+        }
+    } else {
+      for (int t = (lb + P.L - 1) / P.L; t <= (hb - 1) / P.L; ++t) P.task_row0[t] = (int)r;
+    }
+  }
+}
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+  using type = float4;
+  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ void fma(float4 &a, float w, const float4 &x) {
+    a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);
+  }
+  static __device__ __forceinline__ void scale_add(float4 &a, float s, const float4 &x) { fma(a, s, x); }
+  static __device__ __forceinline__ void mul(float4 &a, float s) { a.x *= s; a.y *= s; a.z *= s; a.w *= s; }
+  static __device__ __forceinline__ void div(float4 &a, float s) { a.x /= s; a.y /= s; a.z /= s; a.w /= s; }
+};
+template <>
+struct VecT<1> {
+  using type = float;
+  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ void fma(float &a, float w, const float &x) { a = fmaf(w, x, a); }
+  static __device__ __forceinline__ void scale_add(float &a, float s, const float &x) { a = fmaf(s, x, a); }
+  static __device__ __forceinline__ void mul(float &a, float s) { a *= s; }
+  static __device__ __forceinline__ void div(float &a, float s) { a /= s; }
+};
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) {
+  using V = VecT<VEC>;
+  using vec_t = typename V::type;
+  extern __shared__ __align__(16) float lds_raw[];
+  const int wib = wave_in_block();
+  const int lane = lane_id();
+  const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
+  if (t >= P.T) return;
+  const int L = P.L, H = P.H;
+  float *sc = lds_raw + (size_t)wib * L * (H + 2);        // [L][H] score terms -> weights
+  unsigned *cidx = (unsigned *)(sc + (size_t)L * H);      // [L] column id | ROWEND
+  int *dq = (int *)(cidx + L);                            // [L] flush destinations, in row order
+
+  const int e0 = t * L;
+  const int e1 = min(e0 + L, P.nnz);
+  const int cnt = e1 - e0;
+
+  // ---------------------------------------------------------------- phase A: stage
+  for (int p = lane; p < cnt; p += DGNN_WAVE) {
+    const int c = P.col_ind[e0 + p];
+    cidx[p] = (unsigned)c;
+    if (MODE == MODE_GAT) {
+      if (H == 4) {
+        *(float4 *)(sc + (size_t)p * 4) = *(const float4 *)(P.attn_col + (size_t)c * 4);
+      } else {
+        for (int h = 0; h < H; ++h) sc[(size_t)p * H + h] = P.attn_col[(size_t)c * H + h];
+      }
+    } else if (MODE == MODE_VAL) {
+      for (int h = 0; h < H; ++h) sc[(size_t)p * H + h] = P.edge_val[(size_t)(e0 + p) * H + h];
+    } else {
+      for (int h = 0; h < H; ++h)
+        sc[(size_t)p * H + h] = gmm_weight(P.dim, P.pseudo + (size_t)(e0 + p) * P.dim,
+                                           P.mu + (size_t)h * P.dim, P.inv_sigma + (size_t)h * P.dim);
+    }
+  }
+  wave_lds_sync();
+
+  // ---------------------------------------------------------------- phase B: rows of the group
+  int nflush = 0;
+  {
+    int r = uniform_i32(P.task_row0[t]);
+    int rs = uniform_i32(P.row_ptr[r]);
+    while (true) {
+      const int re = uniform_i32(P.row_ptr[r + 1]);
+      const int a = max(rs, e0) - e0, b = min(re, e1) - e0;
+      if (b > a) {
+        const bool whole = (rs >= e0) && (re <= e1);
+        const int slot = (rs < e0) ? 2 * t : 2 * t + 1;
+        float *slot_ptr = P.slots + (size_t)slot * P.slot_stride;
+        if (MODE == MODE_GAT) {
+          for (int h = 0; h < H; ++h) {
+            const float arh = P.attn_row[(size_t)r * H + h];
+            float mx = DGNN_NEG_INIT;
+            for (int p = a + lane; p < b; p += DGNN_WAVE)
+              mx = fmaxf(mx, leaky_relu(arh + sc[(size_t)p * H + h], P.slope));
+            mx = wave_max(mx);
+            float sm = 0.f;
+            for (int p = a + lane; p < b; p += DGNN_WAVE) {
+              const float pe = expf(leaky_relu(arh + sc[(size_t)p * H + h], P.slope) - mx);
+              sc[(size_t)p * H + h] = pe;
+              sm += pe;
+            }
+            sm = wave_sum(sm);
+            for (int p = a + lane; p < b; p += DGNN_WAVE) {
+              float w = sc[(size_t)p * H + h];
+              if (whole) w = w / sm;                       // exp(e-max)/sum per edge, :102
+              if (P.edge_mask != nullptr) {
+                if (!(P.edge_mask[(size_t)(e0 + p) * H + h] > P.attn_drop)) w = 0.f;   // :95
+                w = drop_scale(w, P.attn_drop);                                       // :104
+              }
+              sc[(size_t)p * H + h] = w;
+            }
+            if (lane == 0) {
+              if (whole) {
+                if (P.edge_max != nullptr) {
+                  P.edge_max[(size_t)r * H + h] = mx;
+                  P.edge_sum[(size_t)r * H + h] = sm;
+                }
+              } else {
+                slot_ptr[P.HF + h] = mx;
+                slot_ptr[P.HF + H + h] = sm;
+              }
+            }
+          }
+        }
+        if (lane == 0) {
+          cidx[b - 1] |= DGNN_ROWEND;
+          dq[nflush] = whole ? r : -(slot + 1);
+        }
+        ++nflush;
+      }
+      if (re >= e1 || r + 1 >= P.m) break;   // second test: never walk past the last row
+      rs = re;
+      ++r;
+    }
+  }
+  wave_lds_sync();
+
+  // ---------------------------------------------------------------- phase C: pipelined gather
+  const int nfb = (P.rowv + DGNN_WAVE - 1) / DGNN_WAVE;
+  for (int fb = 0; fb < nfb; ++fb) {
+    const int vslot = fb * DGNN_WAVE + lane;
+    const bool active = vslot < P.rowv;
+    const int head = active ? (vslot * VEC) / P.F : 0;
+    const size_t lane_off = (size_t)(active ? vslot : 0) * VEC;
+    const float *wbase = sc + head;
+    vec_t acc = V::zero();
+    vec_t ring[DGNN_FAST_U];
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < DGNN_FAST_U; ++k) {
+      ring[k] = V::zero();
+      if (k < cnt) {
+        const unsigned c = uniform_i32((int)(cidx[k] & ~DGNN_ROWEND));
+        if (active) ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
+      }
+    }
+    for (int j = 0; j < cnt; j += DGNN_FAST_U) {
+#pragma unroll
+      for (int k = 0; k < DGNN_FAST_U; ++k) {
+        const int p = j + k;
+        if (p < cnt) {
+          const vec_t x = ring[k];
+          const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
+          if (p + DGNN_FAST_U < cnt) {
+            const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
+            if (active) ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
+          }
+          const float w = wbase[(size_t)p * H];
+          V::fma(acc, w, x);
+          if (ci & DGNN_ROWEND) {
+            const int d = uniform_i32(dq[q]);
+            ++q;
+            float *dst = (d >= 0) ? P.out + (size_t)d * P.HF
+                                  : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+            if (active) *(vec_t *)(dst + lane_off) = acc;
+            acc = V::zero();
+          }
+        }
+      }
+    }
+  }
+}
+
+// Merge the partial slots of rows cut by a group boundary.  One wave per boundary t (1..T-1);
+// the wave of the FIRST boundary inside a row owns that row's merge, pieces are combined in
+// group order: M = max m_p, S = sum s_p*exp(m_p-M), out = sum acc_p*exp(m_p-M) / S.
+template <int MODE>
+__global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
+  const int lane = lane_id();
+  const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) + 1;
+  if (t >= P.T) return;
+  const int L = P.L, H = P.H;
+  const int r = uniform_i32(P.task_row0[t]);
+  const int rs = uniform_i32(P.row_ptr[r]), re = uniform_i32(P.row_ptr[r + 1]);
+  const long long edge = (long long)t * L;
+  if (rs >= edge) return;                    // the row starts exactly on the boundary: not cut here
+  if (rs < edge - L) return;                 // an earlier boundary owns this row
+  const int t_last = (re - 1) / L;
+  // piece i = 0 is the tail slot of group t-1, pieces 1.. are the head slots of groups t..t_last
+  const int npieces = t_last - t + 2;
+  auto slot_of = [&](int i) -> const float * {
+    const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
+    return P.slots + (size_t)s * P.slot_stride;
+  };
+  for (int fb = 0; fb * DGNN_WAVE < P.HF; ++fb) {
+    const int fid = fb * DGNN_WAVE + lane;
+    const bool active = fid < P.HF;
+    const int head = active ? fid / P.F : 0;
+    float acc = 0.f;
+    if (MODE == MODE_GAT) {
+      float M = DGNN_NEG_INIT;
+      for (int i = 0; i < npieces; ++i) M = fmaxf(M, slot_of(i)[P.HF + head]);
+      float S = 0.f;
+      for (int i = 0; i < npieces; ++i) {
+        const float *sp = slot_of(i);
+        const float fct = expf(sp[P.HF + head] - M);
+        S = fmaf(sp[P.HF + H + head], fct, S);
+        if (active) acc = fmaf(sp[fid], fct, acc);
+      }
+      if (active) {
+        P.out[(size_t)r * P.HF + fid] = acc / S;
+        if (P.edge_max != nullptr && fid == head * P.F) {
+          P.edge_max[(size_t)r * H + head] = M;
+          P.edge_sum[(size_t)r * H + head] = S;
+        }
+      }
+    } else {
+      for (int i = 0; i < npieces; ++i)
+        if (active) acc += slot_of(i)[fid];
+      if (active) P.out[(size_t)r * P.HF + fid] = acc;
+    }
+  }
+}
+
+}  // namespace dgnn

@@ -1,67 +1,10 @@
-// GE-SpMM, multi-head SDDMM, edge permute, fused GMMConv and fused EdgeConv:
+// Multi-head SDDMM, edge permute, Gaussian kernels and fused EdgeConv:
 // kernels + C-ABI entry points (include/dgnn_hip.h).
 #include "common.hpp"
 
 using namespace dgnn;
 
 namespace dgnn {
-
-// --------------------------------------------------------------------------- SpMM / GMM
-// One wave per CSR row.  WEIGHT = 0: caller-supplied edge values (GE-SpMM, phase 3 of
-// fused_gatconv_kernel.cu:87-117).  WEIGHT = 1: Gaussian kernel weight computed on the fly
-// from pseudo coordinates (fuseGmm, fused_gmmconv_kernel.cu:24-55): float accumulation of
-// ((p-mu)^2 * sig^2), exponent in DOUBLE as the reference's `exp(-0.5 * gauss)` (:44).
-__device__ __forceinline__ float gauss_weight(int dim, const float *__restrict__ ps,
-                                              const float *__restrict__ mu,
-                                              const float *__restrict__ isg) {
-  float acc = 0.f;
-  for (int d = 0; d < dim; ++d) {
-    const float tmp = ps[d] - mu[d];
-    const float sig = isg[d];
-    acc = fmaf(tmp * tmp * sig, sig, acc);  // nvcc contracts `gauss += tmp*tmp*sig*sig` the same way
-  }
-  return (float)exp(-0.5 * (double)acc);
-}
-
-template <int WEIGHT>
-__global__ __launch_bounds__(DGNN_BLOCK) void k_spmm_row(
-    int m, int H, int F, int dim, const int *__restrict__ row_ptr,
-    const int *__restrict__ col_ind, const float *__restrict__ edge_val,
-    const float *__restrict__ pseudo, const float *__restrict__ mu,
-    const float *__restrict__ inv_sigma, const float *__restrict__ in_feat,
-    float *__restrict__ out) {
-  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
-  if (r >= m) return;
-  const int lane = lane_id();
-  const int lb = row_ptr[r], hb = row_ptr[r + 1];
-  const size_t HF = (size_t)H * F;
-  for (int h = 0; h < H; ++h) {
-    for (int fb = 0; fb < F; fb += DGNN_WAVE) {
-      const int fid = fb + lane;
-      float acc = 0.f;
-      for (int base = lb; base < hb; base += DGNN_WAVE) {
-        const int p = base + lane;
-        float w = 0.f;
-        int c = 0;
-        if (p < hb) {
-          c = col_ind[p];
-          if (WEIGHT == 0)
-            w = edge_val[(size_t)p * H + h];
-          else
-            w = gauss_weight(dim, pseudo + (size_t)p * dim, mu + (size_t)h * dim,
-                             inv_sigma + (size_t)h * dim);
-        }
-        const int n = min(DGNN_WAVE, hb - base);
-        for (int k = 0; k < n; ++k) {
-          const int ck = bcast_i32(c, k);
-          const float wk = bcast_f32(w, k);
-          if (fid < F) acc = fmaf(wk, in_feat[(size_t)ck * HF + (size_t)h * F + fid], acc);
-        }
-      }
-      if (fid < F) out[(size_t)r * HF + (size_t)h * F + fid] = acc;
-    }
-  }
-}
 
 // --------------------------------------------------------------------------- SDDMM
 // out[e,h] = <A[row(e),h,:], B[col(e),h,:]>  (mhsddmm_kernel.cu:5-81).  One wave per row, so
@@ -109,7 +52,7 @@ __global__ void k_gaussian(long long total, int K, int dim, const float *__restr
        t += (long long)gridDim.x * blockDim.x) {
     const long long e = t / K;
     const int k = (int)(t - e * K);
-    gauss[t] = gauss_weight(dim, pseudo + (size_t)e * dim, mu + (size_t)k * dim,
+    gauss[t] = gmm_weight(dim, pseudo + (size_t)e * dim, mu + (size_t)k * dim,
                             inv_sigma + (size_t)k * dim);
   }
 }
@@ -131,7 +74,7 @@ __global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stage1(
   for (int k = 0; k < K; ++k) {
     float g = 0.f;
     if (live)
-      g = gauss_weight(dim, pseudo + (size_t)e * dim, mu + (size_t)k * dim,
+      g = gmm_weight(dim, pseudo + (size_t)e * dim, mu + (size_t)k * dim,
                        inv_sigma + (size_t)k * dim) *
           grad_gauss[(size_t)e * K + k];
     for (int d = 0; d < dim; ++d) {
@@ -266,26 +209,6 @@ const char *dgnn_error_string(int code) {
   }
 }
 
-size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f) {
-  (void)m; (void)nnz; (void)h; (void)f;
-  return 0;
-}
-
-int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
-                  const float *edge_val, const float *in_feat, float *out_feat, void *workspace,
-                  size_t workspace_bytes, void *stream) {
-  (void)workspace; (void)workspace_bytes;
-  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
-  if (!row_ptr || !in_feat || !out_feat || (nnz > 0 && (!col_ind || !edge_val))) return DGNN_ERR_BAD_ARG;
-  if (m == 0) return DGNN_OK;
-  hipLaunchKernelGGL(k_spmm_row<0>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
-                     (hipStream_t)stream, m, h, f, 0, row_ptr, col_ind, edge_val,
-                     (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, in_feat,
-                     out_feat);
-  DGNN_LAUNCH_CHECK();
-  return DGNN_OK;
-}
-
 int dgnn_mhsddmm(int v, int f, int h, int nnz, const int *row_ptr, const int *col_ind,
                  const float *grad, const float *feature, float *out, void *stream) {
   if (v < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
@@ -305,27 +228,6 @@ int dgnn_mhtranspose(int nnz, int h, const int *permute, const float *in, float 
   const long long total = (long long)nnz * h;
   hipLaunchKernelGGL(k_mhtranspose, dim3(grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      total, h, permute, in, out);
-  DGNN_LAUNCH_CHECK();
-  return DGNN_OK;
-}
-
-size_t dgnn_gmm_forward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
-  (void)nodes; (void)nnz; (void)kernels; (void)embed;
-  return 0;
-}
-
-int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
-                     const int *col_ind, const float *node_feat, const float *pseudo,
-                     const float *mu, const float *inv_sigma, float *out, void *workspace,
-                     size_t workspace_bytes, void *stream) {
-  (void)workspace; (void)workspace_bytes;
-  if (nodes < 0 || nnz < 0 || kernels <= 0 || dim <= 0 || embed <= 0) return DGNN_ERR_BAD_ARG;
-  if (!csr_ptr || !node_feat || !mu || !inv_sigma || !out || (nnz > 0 && (!col_ind || !pseudo)))
-    return DGNN_ERR_BAD_ARG;
-  if (nodes == 0) return DGNN_OK;
-  hipLaunchKernelGGL(k_spmm_row<1>, dim3(blocks_for_waves(nodes)), dim3(DGNN_BLOCK), 0,
-                     (hipStream_t)stream, nodes, kernels, embed, dim, csr_ptr, col_ind,
-                     (const float *)nullptr, pseudo, mu, inv_sigma, node_feat, out);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

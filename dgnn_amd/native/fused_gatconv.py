@@ -92,38 +92,56 @@ def gat_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
     return out
 
 
+def gat_row_dot(grad, out_feat):
+    """-> S [m,h] = <grad[r,h,:], out_feat[r,h,:]> (the row term of the backward)."""
+    L.f32(grad, "grad", 3), L.f32(out_feat, "out_feat", 3)
+    m, h, f = grad.size(0), grad.size(1), grad.size(2)
+    with torch.cuda.device(grad.device):
+        S = torch.empty((m, h), dtype=torch.float32, device=grad.device)
+        rc = L.lib().dgnn_gat_row_dot(m, h, f, L.p(grad), L.p(out_feat), L.p(S), L.stream_of(grad))
+    L.check(rc, "dgnn_gat_row_dot")
+    return S
+
+
 def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max,
-                 edge_sum, edge_mask, in_feat, attn_row, attn_col, grad, out_feat=None):
+                 edge_sum, edge_mask, in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None):
     """-> [grad_feat, grad_attn_row, grad_attn_col]   (fused_gatconv.cpp:104-166).
 
-    ``out_feat`` (keyword, not in the reference signature) is the saved forward output; passing
-    it removes one whole gather pass from the backward (see include/dgnn_hip.h)."""
-    for t, n in ((row_ptr, "row_ptr"), (col_ind, "col_ind"), (col_ptr, "col_ptr"),
-                 (row_ind, "row_ind"), (permute, "permute")):
-        L.i32(t, n)
+    ``out_feat`` / ``row_dot`` (keywords, not in the reference signature): the saved forward
+    output, or the precomputed row term; passing either removes one whole gather pass from the
+    backward (see include/dgnn_hip.h).  Rows (m = len(row_ptr)-1) and columns
+    (n = len(col_ptr)-1 = in_feat.size(0)) may differ (row/column partitions)."""
+    for t, nm in ((row_ptr, "row_ptr"), (col_ind, "col_ind"), (col_ptr, "col_ptr"),
+                  (row_ind, "row_ind"), (permute, "permute")):
+        L.i32(t, nm)
     L.f32(edge_max, "edge_max", 2), L.f32(edge_sum, "edge_sum", 2), L.f32(in_feat, "in_feat", 3)
     L.f32(attn_row, "attn_row", 2), L.f32(attn_col, "attn_col", 2), L.f32(grad, "grad", 3)
     m, nnz = row_ptr.size(0) - 1, col_ind.size(0)
+    n = col_ptr.size(0) - 1
     h, f = in_feat.size(1), in_feat.size(2)          # fused_gatconv_kernel.cu:1049-1050
-    if in_feat.size(0) != m or col_ptr.size(0) != m + 1:
-        raise L.DgnnError("gat_backward needs a square adjacency (reference: "
-                          "fused_gatconv_kernel.cu:1013 launches m blocks for the columns)")
+    if in_feat.size(0) != n or attn_col.size(0) != n:
+        raise L.DgnnError("gat_backward: in_feat/attn_col rows must equal len(col_ptr)-1")
+    if grad.size(0) != m or attn_row.size(0) != m or edge_max.size(0) != m or edge_sum.size(0) != m:
+        raise L.DgnnError("gat_backward: grad/attn_row/edge_max/edge_sum rows must equal len(row_ptr)-1")
     attn_drop = float(attn_drop)
     if attn_drop > 0.0:
         L.f32(edge_mask, "edge_mask", 2)
     if out_feat is not None:
         L.f32(out_feat, "out_feat", 3)
+    if row_dot is not None:
+        L.f32(row_dot, "row_dot", 2)
+    have = 1 if (out_feat is not None or row_dot is not None) else 0
     with torch.cuda.device(in_feat.device):
-        grad_feat = torch.empty((m, h, f), dtype=torch.float32, device=in_feat.device)
+        grad_feat = torch.empty((n, h, f), dtype=torch.float32, device=in_feat.device)
         grad_attn_row = torch.empty((m, h), dtype=torch.float32, device=in_feat.device)
-        grad_attn_col = torch.empty((m, h), dtype=torch.float32, device=in_feat.device)
-        nb = L.lib().dgnn_gat_backward_workspace_bytes(m, nnz, h, f, 1 if out_feat is not None else 0)
+        grad_attn_col = torch.empty((n, h), dtype=torch.float32, device=in_feat.device)
+        nb = L.lib().dgnn_gat_backward_workspace_bytes(m, n, nnz, h, f, have)
         ws = L.workspace(nb, in_feat)
         rc = L.lib().dgnn_gat_backward(
-            m, nnz, h, f, float(negative_slope), attn_drop, L.p(row_ptr), L.p(col_ind), L.p(col_ptr),
-            L.p(row_ind), L.p(permute), L.p(edge_max), L.p(edge_sum),
+            m, n, nnz, h, f, float(negative_slope), attn_drop, L.p(row_ptr), L.p(col_ind),
+            L.p(col_ptr), L.p(row_ind), L.p(permute), L.p(edge_max), L.p(edge_sum),
             L.p(edge_mask) if attn_drop > 0.0 else None, L.p(in_feat), L.p(attn_row), L.p(attn_col),
-            L.p(grad), L.p(out_feat), L.p(grad_feat), L.p(grad_attn_row), L.p(grad_attn_col),
-            L.p(ws), nb, L.stream_of(in_feat))
+            L.p(grad), L.p(out_feat), L.p(row_dot), L.p(grad_feat), L.p(grad_attn_row),
+            L.p(grad_attn_col), L.p(ws), nb, L.stream_of(in_feat))
     L.check(rc, "dgnn_gat_backward")
     return [grad_feat, grad_attn_row, grad_attn_col]

@@ -82,30 +82,42 @@ int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
                            float *edge_max, float *edge_sum, float *out_feat,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* Scratch for dgnn_gat_backward.  have_out_feat != 0 when the caller will pass the saved
- * forward output (then no recompute buffer is needed). */
-size_t dgnn_gat_backward_workspace_bytes(int m, int nnz, int h, int f, int have_out_feat);
+/* S[r,h] = <grad[r,h,:], out_feat[r,h,:]>: the per-row term sum_j a_j g_j of
+ * fused_backward_kernel's first sweep (fused_gatconv_kernel.cu:906-931) as one dense dot
+ * product.  dgnn_gat_backward computes it itself when given out_feat; it is exported for
+ * callers that hold rows and columns in different places (row-partitioned multi-GPU). */
+int dgnn_gat_row_dot(int m, int h, int f, const float *grad, const float *out_feat,
+                     float *row_dot, void *stream);
+
+/* Scratch for dgnn_gat_backward.  have_row_term != 0 when the caller will pass out_feat or
+ * row_dot (then no recompute buffer is needed). */
+size_t dgnn_gat_backward_workspace_bytes(int m, int n, int nnz, int h, int f, int have_row_term);
 
 /* Fused GAT backward.  Replaces gat_backward(), fused_gatconv_kernel.cu:998-1038, i.e. the
  * three kernels mhspmm_backward_kernel :712-763, mhsddmm :814-890 and
  * fused_backward_kernel :892-968, and the [nnz,h] grad_edge_csr temporary (:1054).
  * Arguments follow the reference binding gat_backward (fused_gatconv.cpp:104-166).
+ *   m rows (destinations) x n columns (sources).  The reference assumes m == n (:1013 launches
+ *   m blocks for the columns); rectangular blocks are what a row/column partition produces.
+ *   row_ptr [m+1], col_ind [nnz]; col_ptr [n+1], row_ind [nnz], permute [nnz];
+ *   edge_max, edge_sum, attn_row [m,h]; attn_col [n,h]; in_feat [n,h,f]; grad [m,h,f].
  *   out_feat [m,h,f]  OPTIONAL saved forward output.  With it the row term
  *                     S[r,h] = sum_j a_j g_j of :906-931 is computed as <grad[r,h,:],
  *                     out_feat[r,h,:]> (identical algebraically) and the whole backward
- *                     needs ONE gather pass over the edges.  NULL = recompute it (one extra
- *                     forward pass, still no [nnz,h,*] temporaries beyond [nnz,h]).
+ *                     needs ONE gather pass over the edges.
+ *   row_dot [m,h]     OPTIONAL precomputed S (dgnn_gat_row_dot); takes precedence over out_feat.
+ *                     Both NULL = rebuild out_feat with one extra forward pass (the reference
+ *                     signature carries neither).
  *   grad_feat [n,h,f], grad_attn_row [m,h], grad_attn_col [n,h]: outputs, fully written
- *   (no pre-zeroing by the caller; the reference zeroes grad_attn_col itself, :1057).
- * Square adjacency assumed, as in the reference (:1013 launches m blocks for columns). */
-int dgnn_gat_backward(int m, int nnz, int h, int f, float negative_slope, float attn_drop,
+ *   (no pre-zeroing by the caller; the reference zeroes grad_attn_col itself, :1057). */
+int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
                       const int *row_ptr, const int *col_ind, const int *col_ptr,
                       const int *row_ind, const int *permute, const float *edge_max,
                       const float *edge_sum, const float *edge_mask, const float *in_feat,
                       const float *attn_row, const float *attn_col, const float *grad,
-                      const float *out_feat, float *grad_feat, float *grad_attn_row,
-                      float *grad_attn_col, void *workspace, size_t workspace_bytes,
-                      void *stream);
+                      const float *out_feat, const float *row_dot, float *grad_feat,
+                      float *grad_attn_row, float *grad_attn_col, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------- GE-SpMM / SDDMM / permute ---- */
 

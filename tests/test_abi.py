@@ -41,11 +41,11 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_queries_are_pure_host_functions():
     from dgnn_amd import _lib
     lib = _lib.lib()
-    a = lib.dgnn_gat_backward_workspace_bytes(1000, 5000, 4, 64, 1)
-    b = lib.dgnn_gat_backward_workspace_bytes(1000, 5000, 4, 64, 0)
+    a = lib.dgnn_gat_backward_workspace_bytes(1000, 1000, 5000, 4, 64, 1)
+    b = lib.dgnn_gat_backward_workspace_bytes(1000, 1000, 5000, 4, 64, 0)
     assert b > a > 0                         # the recompute path needs the extra [m,h,f] buffer
     assert lib.dgnn_gaussian_backward_workspace_bytes(1000, 3, 2) > 0
-    assert lib.dgnn_gat_backward_workspace_bytes(-1, 5, 4, 64, 1) == 0
+    assert lib.dgnn_gat_backward_workspace_bytes(-1, 5, 5, 4, 64, 1) == 0
 
 
 def test_no_cpu_fallback():
