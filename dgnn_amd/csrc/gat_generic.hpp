@@ -172,37 +172,63 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_bwd_col(
 }
 
 // grad_attn_row[r,h] = sum over the row's edges of dE[e,h]  (fused_backward_kernel :961-967).
-// One 16-lane group per row; a row longer than LONG_ROW edges is finished by the whole block.
+// One 16-lane group per row (H == 4: one float4 = one edge per lane and step, 256 B per group
+// and step); a row longer than DGNN_ROWSUM_LONG edges is finished by the whole block with a
+// fixed reduction tree, so the result is deterministic.
 #define DGNN_ROWSUM_LONG 4096
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,
                                                             const int *__restrict__ row_ptr,
                                                             const float *__restrict__ dE,
                                                             float *__restrict__ grad_attn_row) {
   __shared__ float red[DGNN_BLOCK];
+  __shared__ int any_long;
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
   const int r0 = blockIdx.x * 16;
   const int r = r0 + grp;
+  if (threadIdx.x == 0) any_long = 0;
+  __syncthreads();
   if (r < m) {
     const int lb = row_ptr[r], hb = row_ptr[r + 1];
-    if (hb - lb <= DGNN_ROWSUM_LONG) {
-      if (H <= 16 && (16 % H) == 0) {
-        // the 16 lanes walk the row's contiguous [deg*H] slab; since 16 % H == 0 a lane
-        // always lands on head q % H
+    if (hb - lb > DGNN_ROWSUM_LONG) {
+      if (q == 0) any_long = 1;
+    } else if (H == 4 && (((uintptr_t)dE) & 15u) == 0) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 *d4 = (const float4 *)dE;
+      int p = lb + q;
+      for (; p + 48 < hb; p += 64) {   // 4 independent loads in flight per lane
+        const float4 v0 = d4[p], v1 = d4[p + 16], v2 = d4[p + 32], v3 = d4[p + 48];
+        s.x += (v0.x + v1.x) + (v2.x + v3.x);
+        s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z);
+        s.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; p < hb; p += 16) {
+        const float4 v = d4[p];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      s.x = row16_reduce(s.x, OpSum());
+      s.y = row16_reduce(s.y, OpSum());
+      s.z = row16_reduce(s.z, OpSum());
+      s.w = row16_reduce(s.w, OpSum());
+      if (q == 0) *(float4 *)(grad_attn_row + (size_t)r * 4) = s;
+    } else if (H <= 16 && (16 % H) == 0) {
+      // the 16 lanes walk the row's contiguous [deg*H] slab; since 16 % H == 0 a lane
+      // always lands on head q % H
+      float s = 0.f;
+      const size_t beg = (size_t)lb * H, end = (size_t)hb * H;
+      for (size_t i = beg + q; i < end; i += 16) s += dE[i];
+      for (int st = H; st < 16; st <<= 1) s += __shfl_xor(s, st, 16);
+      if (q < H) grad_attn_row[(size_t)r * H + q] = s;
+    } else {
+      for (int h = q; h < H; h += 16) {
         float s = 0.f;
-        const size_t beg = (size_t)lb * H, end = (size_t)hb * H;
-        for (size_t i = beg + q; i < end; i += 16) s += dE[i];
-        for (int st = H; st < 16; st <<= 1) s += __shfl_xor(s, st, 16);
-        if (q < H) grad_attn_row[(size_t)r * H + q] = s;
-      } else {
-        for (int h = q; h < H; h += 16) {
-          float s = 0.f;
-          for (int p = lb; p < hb; ++p) s += dE[(size_t)p * H + h];
-          grad_attn_row[(size_t)r * H + h] = s;
-        }
+        for (int p = lb; p < hb; ++p) s += dE[(size_t)p * H + h];
+        grad_attn_row[(size_t)r * H + h] = s;
       }
     }
   }
-  // long rows: the whole block cooperates, fixed reduction tree => deterministic
+  __syncthreads();
+  if (!any_long) return;
   for (int g = 0; g < 16; ++g) {
     const int rr = r0 + g;
     if (rr >= m) break;

@@ -85,7 +85,10 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
                    float *edge_max, float *edge_sum, float *out_feat, void *workspace,
                    size_t workspace_bytes, hipStream_t st) {
   if (m == 0) return DGNN_OK;
-  if (fwd_fast_ok(m, h) && !(h == 4 && !aligned16(attn_col))) {
+  // the H == 4 kernels move the per-row / per-edge scalars as float4
+  const bool h4_aligned = aligned16(attn_col) && aligned16(attn_row) && aligned16(edge_mask) &&
+                          aligned16(edge_max) && aligned16(edge_sum);
+  if (fwd_fast_ok(m, h) && (h != 4 || h4_aligned)) {
     GatherParams P = {};
     P.m = m; P.nnz = nnz; P.H = h; P.F = f;
     P.attn_drop = attn_drop; P.slope = slope;

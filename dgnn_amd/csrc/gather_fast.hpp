@@ -25,7 +25,9 @@
 
 namespace dgnn {
 
+#ifndef DGNN_FAST_U
 #define DGNN_FAST_U 8          // feature-row gathers in flight per wave
+#endif
 #define DGNN_FAST_HMAX 8
 #define DGNN_ROWEND 0x80000000u
 
@@ -148,7 +150,54 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         const bool whole = (rs >= e0) && (re <= e1);
         const int slot = (rs < e0) ? 2 * t : 2 * t + 1;
         float *slot_ptr = P.slots + (size_t)slot * P.slot_stride;
-        if (MODE == MODE_GAT) {
+        if (MODE == MODE_GAT && H == 4 && (b - a) <= DGNN_WAVE) {
+          // common case: the whole segment fits one wave pass, all four heads at once
+          const int p = a + lane;
+          const bool live = p < b;
+          const float4 ar4 = *(const float4 *)(P.attn_row + (size_t)r * 4);
+          float4 e4 = make_float4(DGNN_NEG_INIT, DGNN_NEG_INIT, DGNN_NEG_INIT, DGNN_NEG_INIT);
+          if (live) {
+            const float4 c4 = *(const float4 *)(sc + (size_t)p * 4);
+            e4.x = leaky_relu(ar4.x + c4.x, P.slope);
+            e4.y = leaky_relu(ar4.y + c4.y, P.slope);
+            e4.z = leaky_relu(ar4.z + c4.z, P.slope);
+            e4.w = leaky_relu(ar4.w + c4.w, P.slope);
+          }
+          float4 mx;
+          mx.x = wave_max(e4.x); mx.y = wave_max(e4.y); mx.z = wave_max(e4.z); mx.w = wave_max(e4.w);
+          float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (live) {
+            pe.x = expf(e4.x - mx.x); pe.y = expf(e4.y - mx.y);
+            pe.z = expf(e4.z - mx.z); pe.w = expf(e4.w - mx.w);
+          }
+          float4 sm;
+          sm.x = wave_sum(pe.x); sm.y = wave_sum(pe.y); sm.z = wave_sum(pe.z); sm.w = wave_sum(pe.w);
+          if (live) {
+            float4 w4 = pe;
+            if (whole) { w4.x /= sm.x; w4.y /= sm.y; w4.z /= sm.z; w4.w /= sm.w; }   // :102
+            if (P.edge_mask != nullptr) {
+              const float4 mk = *(const float4 *)(P.edge_mask + (size_t)(e0 + p) * 4);
+              if (!(mk.x > P.attn_drop)) w4.x = 0.f;                                 // :95
+              if (!(mk.y > P.attn_drop)) w4.y = 0.f;
+              if (!(mk.z > P.attn_drop)) w4.z = 0.f;
+              if (!(mk.w > P.attn_drop)) w4.w = 0.f;
+              w4.x = drop_scale(w4.x, P.attn_drop); w4.y = drop_scale(w4.y, P.attn_drop);  // :104
+              w4.z = drop_scale(w4.z, P.attn_drop); w4.w = drop_scale(w4.w, P.attn_drop);
+            }
+            *(float4 *)(sc + (size_t)p * 4) = w4;
+          }
+          if (lane == 0) {
+            if (whole) {
+              if (P.edge_max != nullptr) {
+                *(float4 *)(P.edge_max + (size_t)r * 4) = mx;
+                *(float4 *)(P.edge_sum + (size_t)r * 4) = sm;
+              }
+            } else {
+              *(float4 *)(slot_ptr + P.HF) = mx;
+              *(float4 *)(slot_ptr + P.HF + 4) = sm;
+            }
+          }
+        } else if (MODE == MODE_GAT) {
           for (int h = 0; h < H; ++h) {
             const float arh = P.attn_row[(size_t)r * H + h];
             float mx = DGNN_NEG_INIT;
@@ -264,11 +313,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
     const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
     return P.slots + (size_t)s * P.slot_stride;
   };
-  for (int fb = 0; fb * DGNN_WAVE < P.HF; ++fb) {
-    const int fid = fb * DGNN_WAVE + lane;
-    const bool active = fid < P.HF;
-    const int head = active ? fid / P.F : 0;
-    float acc = 0.f;
+  const bool vec4 = (P.F % 4 == 0) && ((((uintptr_t)P.out) & 15u) == 0);
+  const int vw = vec4 ? 4 : 1;
+  const int nslots = P.HF / vw;
+  for (int fb = 0; fb * DGNN_WAVE < nslots; ++fb) {
+    const int vs = fb * DGNN_WAVE + lane;
+    const bool active = vs < nslots;
+    const int fid = (active ? vs : 0) * vw;
+    const int head = fid / P.F;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == MODE_GAT) {
       float M = DGNN_NEG_INIT;
       for (int i = 0; i < npieces; ++i) M = fmaxf(M, slot_of(i)[P.HF + head]);
@@ -277,10 +330,22 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
         const float *sp = slot_of(i);
         const float fct = expf(sp[P.HF + head] - M);
         S = fmaf(sp[P.HF + H + head], fct, S);
-        if (active) acc = fmaf(sp[fid], fct, acc);
+        if (active) {
+          if (vec4) {
+            const float4 v = *(const float4 *)(sp + fid);
+            acc[0] = fmaf(v.x, fct, acc[0]); acc[1] = fmaf(v.y, fct, acc[1]);
+            acc[2] = fmaf(v.z, fct, acc[2]); acc[3] = fmaf(v.w, fct, acc[3]);
+          } else {
+            acc[0] = fmaf(sp[fid], fct, acc[0]);
+          }
+        }
       }
       if (active) {
-        P.out[(size_t)r * P.HF + fid] = acc / S;
+        if (vec4)
+          *(float4 *)(P.out + (size_t)r * P.HF + fid) =
+              make_float4(acc[0] / S, acc[1] / S, acc[2] / S, acc[3] / S);
+        else
+          P.out[(size_t)r * P.HF + fid] = acc[0] / S;
         if (P.edge_max != nullptr && fid == head * P.F) {
           P.edge_max[(size_t)r * H + head] = M;
           P.edge_sum[(size_t)r * H + head] = S;
@@ -288,8 +353,21 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
       }
     } else {
       for (int i = 0; i < npieces; ++i)
-        if (active) acc += slot_of(i)[fid];
-      if (active) P.out[(size_t)r * P.HF + fid] = acc;
+        if (active) {
+          const float *sp = slot_of(i);
+          if (vec4) {
+            const float4 v = *(const float4 *)(sp + fid);
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+          } else {
+            acc[0] += sp[fid];
+          }
+        }
+      if (active) {
+        if (vec4)
+          *(float4 *)(P.out + (size_t)r * P.HF + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else
+          P.out[(size_t)r * P.HF + fid] = acc[0];
+      }
     }
   }
 }
