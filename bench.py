@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="products", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the row-partitioned path even with one rank (sanity check of dgnn_amd.dist)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,7 +157,7 @@ def main():
     attn_col = (torch.rand((n, H), device=device, generator=gen) - 0.4)
     grad_out = (torch.rand((n, H, F), device=device, generator=gen) - 0.5)
 
-    if world > 1:
+    if world > 1 or args.force_dist:
         from dgnn_amd.dist import PartitionedGAT
         runner = PartitionedGAT(g, world, rank, device)
         step_fn = lambda: runner.step(in_feat, attn_row, attn_col, grad_out, SLOPE)
@@ -192,7 +194,7 @@ def main():
     # Per-phase timing with events on the launch stream (torch's current stream), single GPU:
     # the forward call and the backward call each are dominated by one gather kernel.
     roof = None
-    if world == 1:
+    if world == 1 and not args.force_dist:
         from dgnn_amd.native import fused_gatconv
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         tf = tb = 0.0

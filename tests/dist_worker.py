@@ -1,0 +1,105 @@
+"""Worker for the multi-process tests of dgnn_amd.dist (spawned by test_dist.py).
+
+mode "cpu": gloo backend, CPU tensors, compute through a CPU stand-in built on the oracle
+            (test infrastructure: exercises the partition, block extraction, inverse
+            permutation and collectives without a GPU).
+mode "gpu": gloo backend, every rank on cuda:0, compute through the real HIP kernels.
+Each rank writes its local results to <out_dir>/rank<r>.npz; the parent assembles and checks.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+class OracleOps:
+    """CPU stand-in for the kernel set PartitionedGAT needs (rectangular blocks)."""
+
+    def __init__(self):
+        import oracle
+        self.o = oracle
+
+    @staticmethod
+    def _t(a, dtype=None):
+        return torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
+
+    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat):
+        out, emax, esum = self.o.gat_forward(attn_row.numpy(), attn_col.numpy(), row_ptr.numpy(),
+                                             col_ind.numpy(), slope, in_feat.numpy(), 0.0)
+        return self._t(out), self._t(emax), self._t(esum)
+
+    def row_dot(self, grad, out):
+        return (grad.double() * out.double()).sum(-1).float()
+
+    def transpose(self, ptr, ind, n_cols):
+        cp, ri, pm = self.o.csr2csc(ptr.numpy(), ind.numpy(), n_cols)
+        return self._t(cp), self._t(ri), self._t(pm)
+
+    def gat_backward(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
+                     in_feat, attn_row, attn_col, grad, row_dot):
+        """Same dataflow as the HIP backward: one pass over the CSC, d written to CSR order through
+        `permute`, row sums over the block's own row_ptr."""
+        cp, ri, pm = col_ptr.numpy().astype(np.int64), row_ind.numpy().astype(np.int64), permute.numpy().astype(np.int64)
+        rp = row_ptr.numpy().astype(np.int64)
+        n, m = cp.size - 1, rp.size - 1
+        col = np.repeat(np.arange(n), np.diff(cp))
+        ar, ac = attn_row.double().numpy(), attn_col.double().numpy()
+        em, es, S = edge_max.double().numpy(), edge_sum.double().numpy(), row_dot.double().numpy()
+        x, g = in_feat.double().numpy(), grad.double().numpy()
+        e = ar[ri] + ac[col]
+        neg = e <= 0
+        e = np.where(e > 0, e, e * slope)
+        a = np.exp(e - em[ri]) / es[ri]
+        dots = np.einsum("ehf,ehf->eh", g[ri], x[col])
+        d = a * (dots - S[ri]) * np.where(e < 0, slope, 1.0)
+        gf = np.zeros_like(x)
+        np.add.at(gf, col, a[:, :, None] * g[ri])
+        gc = np.zeros_like(ac)
+        np.add.at(gc, col, d)
+        dE = np.zeros_like(d)
+        dE[pm] = d                                   # CSC order -> the block's CSR order
+        assert np.array_equal(np.sort(pm), np.arange(pm.size)), "permute must be a permutation"
+        rows_csr = np.repeat(np.arange(m), np.diff(rp))
+        assert np.array_equal(rows_csr[pm], ri), "permute / row_ptr of the backward block disagree"
+        gr = np.zeros((m, ar.shape[1]))
+        np.add.at(gr, rows_csr, dE)
+        return self._t(gf, np.float32), self._t(gr, np.float32), self._t(gc, np.float32)
+
+
+def run(rank, world, mode, port, out_dir, graph_spec, h, f):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import gat_inputs, rmat_graph
+    from dgnn_amd.dist import PartitionedGAT
+    g = rmat_graph(*graph_spec)
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
+    device = torch.device("cuda:0" if mode == "gpu" else "cpu")
+    G = {k: torch.from_numpy(g[k]).to(device) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
+    ops = None if mode == "gpu" else OracleOps()
+    runner = PartitionedGAT(G, world, rank, device, ops=ops)
+    lo, hi = runner.lo, runner.hi
+    t = lambda a: torch.from_numpy(a).to(device)
+    out = runner.forward(t(in_feat[lo:hi]), t(attn_row[lo:hi]), t(attn_col[lo:hi]), 0.2)
+    gf, gr, gc = runner.backward(t(grad[lo:hi]))
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, out=out.cpu().numpy(),
+             gf=gf.cpu().numpy(), gr=gr.cpu().numpy(), gc=gc.cpu().numpy(),
+             nnz_fwd=runner.nnz_fwd, nnz_bwd=runner.nnz_bwd)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    rank, world, mode, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    spec = tuple(int(v) for v in sys.argv[6].split(","))
+    run(rank, world, mode, port, out_dir, spec, int(sys.argv[7]), int(sys.argv[8]))
