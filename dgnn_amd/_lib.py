@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdgnn_hip.so")
+# DGNN_HIP_LIB selects another build of the same library (kernel tuning A/B runs)
+LIB_PATH = os.environ.get("DGNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgnn_hip.so")
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

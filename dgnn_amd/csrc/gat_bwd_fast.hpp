@@ -46,10 +46,15 @@ struct BwdParams {
   float *slots;        // [2T][slot_stride]
 };
 
-static inline int bwd_group_size(int H) { return H <= 4 ? 128 : 64; }
+static inline int bwd_group_size(int H) {
+  const int dflt = H <= 4 ? 256 : 128;
+  const int v = env_int("DGNN_BWD_L", dflt);   // tuning override: 64, 128 or 256
+  if (!(v == 64 || v == 128 || v == 256)) return dflt;
+  return (H > 4 && v > 128) ? 128 : v;
+}
 static inline size_t bwd_lds_bytes(int H, int L) {
-  // per wave: raw float4 [L][H] + ridl[L] + kof[L] + colk[L] + dq[L] + stream[2L]
-  return (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)L * H * 16 + (size_t)L * 6 * 4);
+  // per wave: cell float2 [L][H] + kof[L] + colk[L] + dq[L] + stream[2L]
+  return (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)L * H * 2 + (size_t)L * 5) * sizeof(float);
 }
 
 // Per destination row: S[r,h] = <grad[r,h,:], out[r,h,:]> and the packed statistics the CSC pass
@@ -92,30 +97,43 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
   }
 }
 
+// HC = heads (compile time), EPL = edges per lane; the group holds L = 64*EPL CSC entries.
+// The gathered row statistics stay in registers between staging and the coefficient pass, so
+// LDS keeps only 8 B per (edge, head): {signed weight, B} with d written over B afterwards.
+template <int HC, int EPL>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   extern __shared__ __align__(16) float lds_raw[];
+  constexpr int L = DGNN_WAVE * EPL;
+  constexpr int H = HC;
   const int wib = wave_in_block();
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
-  const int L = P.L, H = P.H;
-  const size_t per_wave_floats = (size_t)L * H * 4 + (size_t)L * 6;
-  float4 *raw = (float4 *)(lds_raw + (size_t)wib * per_wave_floats);   // [L][H]
-  int *ridl = (int *)(raw + (size_t)L * H);                            // [L] row id of edge p
-  unsigned *kof = (unsigned *)(ridl + L);                              // [L] column ordinal | END
-  int *colk = (int *)(kof + L);                                        // [L] column id of ordinal k
-  int *dq = colk + L;                                                  // [L] flush destination of ordinal k
-  unsigned *stream = (unsigned *)(dq + L);                             // [2L] load stream
+  constexpr size_t per_wave_floats = (size_t)L * H * 2 + (size_t)L * 5;
+  float2 *cell = (float2 *)(lds_raw + (size_t)wib * per_wave_floats);  // [L][H] {±w, B -> d}
+  unsigned *kof = (unsigned *)(cell + (size_t)L * H);                   // [L] column ordinal | END
+  int *colk = (int *)(kof + L);                                         // [L] column id of ordinal k
+  int *dq = colk + L;                                                   // [L] flush destination of ordinal k
+  unsigned *stream = (unsigned *)(dq + L);                              // [2L] load stream
 
   const int e0 = t * L;
   const int e1 = min(e0 + L, P.nnz);
   const int cnt = e1 - e0;
 
-  // ---------------------------------------------------------------- phase A: stage row data
-  for (int p = lane; p < cnt; p += DGNN_WAVE) {
-    const int rid = P.row_ind[e0 + p];
-    ridl[p] = rid;
-    for (int h = 0; h < H; ++h) raw[(size_t)p * H + h] = P.rowstat[(size_t)rid * H + h];
+  // ---------------------------------------------------------------- phase A: stage row data (registers)
+  int rid[EPL];
+  float4 st[EPL][HC];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int p = j * DGNN_WAVE + lane;
+    rid[j] = (p < cnt) ? P.row_ind[e0 + p] : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int p = j * DGNN_WAVE + lane;
+#pragma unroll
+    for (int h = 0; h < HC; ++h)
+      st[j][h] = (p < cnt) ? P.rowstat[(size_t)rid[j] * HC + h] : make_float4(0.f, 0.f, 1.f, 0.f);
   }
 
   // ---------------------------------------------------------------- columns of the group
@@ -151,24 +169,37 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   wave_lds_sync();
 
   // ---------------------------------------------------------------- per-edge coefficients
-  for (int p = lane; p < cnt; p += DGNN_WAVE) {
-    const unsigned kk = kof[p];
-    const int k = (int)(kk & DGNN_BWD_IDMASK);
-    const int c = colk[k];
-    stream[p + k + 1] = (unsigned)ridl[p] | (kk & DGNN_BWD_END);
-    const int pos = (P.edge_mask != nullptr) ? P.permute[e0 + p] : 0;
-    for (int h = 0; h < H; ++h) {
-      const float4 st = raw[(size_t)p * H + h];              // {attn_row, edge_max, edge_sum, S}
-      const float e = leaky_relu(st.x + P.attn_col[(size_t)c * H + h], P.slope);
-      const float a = expf(e - st.y) / st.z;                 // :747
-      float w = a;
-      if (P.edge_mask != nullptr) {
-        if (!(P.edge_mask[(size_t)pos * H + h] > P.attn_drop)) w = 0.f;   // :738
-        w = w / (1 - P.attn_drop);                                        // :749 (float divide)
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int p = j * DGNN_WAVE + lane;
+    if (p < cnt) {
+      const unsigned kk = kof[p];
+      const int k = (int)(kk & DGNN_BWD_IDMASK);
+      const int c = colk[k];
+      stream[p + k + 1] = (unsigned)rid[j] | (kk & DGNN_BWD_END);
+      const int pos = (P.edge_mask != nullptr) ? P.permute[e0 + p] : 0;
+      float ac[HC];
+      if (HC == 4) {
+        const float4 a4 = *(const float4 *)(P.attn_col + (size_t)c * 4);
+        ac[0] = a4.x; ac[1 % HC] = a4.y; ac[2 % HC] = a4.z; ac[3 % HC] = a4.w;
+      } else {
+#pragma unroll
+        for (int h = 0; h < HC; ++h) ac[h] = P.attn_col[(size_t)c * HC + h];
       }
-      const bool neg = e < 0.f;                                           // :953
-      const float B = a * st.w * (neg ? P.slope : 1.f);
-      raw[(size_t)p * H + h] = make_float4(neg ? -w : w, B, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < HC; ++h) {
+        const float4 s4 = st[j][h];                            // {attn_row, edge_max, edge_sum, S}
+        const float e = leaky_relu(s4.x + ac[h], P.slope);
+        const float a = expf(e - s4.y) / s4.z;                 // :747
+        float w = a;
+        if (P.edge_mask != nullptr) {
+          if (!(P.edge_mask[(size_t)pos * HC + h] > P.attn_drop)) w = 0.f;   // :738
+          w = w / (1 - P.attn_drop);                                         // :749 (float divide)
+        }
+        const bool neg = e < 0.f;                                            // :953
+        const float B = a * s4.w * (neg ? P.slope : 1.f);
+        cell[(size_t)p * HC + h] = make_float2(neg ? -w : w, B);
+      }
     }
   }
   wave_lds_sync();
@@ -210,8 +241,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           ++k;
         } else {
           const int p = it - (k + 1);
-          float4 *cell = raw + (size_t)p * H + head;
-          const float2 wb = *(const float2 *)cell;
+          float2 *cp = cell + (size_t)p * HC + head;
+          const float2 wb = *cp;
           const float w = fabsf(wb.x);
           const float sl = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
           float dot = fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
@@ -222,7 +253,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           acc.z = fmaf(w, x.z, acc.z);
           acc.w = fmaf(w, x.w, acc.w);
           dsum += d;
-          if (head_leader) ((float *)cell)[2] = d;
+          if (head_leader) cp->y = d;     // B is dead after this read: keep d in its place
           if (v & DGNN_BWD_END) {
             const int dst = uniform_i32(dq[k]);
             if (dst >= 0) {
@@ -243,16 +274,18 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   wave_lds_sync();
 
   // ---------------------------------------------------------------- d_i to CSR order
-  for (int p = lane; p < cnt; p += DGNN_WAVE) {
-    const size_t pos = (size_t)P.permute[e0 + p];
-    if (H == 4) {
-      const float4 d4 = make_float4(((const float *)&raw[(size_t)p * 4 + 0])[2],
-                                    ((const float *)&raw[(size_t)p * 4 + 1])[2],
-                                    ((const float *)&raw[(size_t)p * 4 + 2])[2],
-                                    ((const float *)&raw[(size_t)p * 4 + 3])[2]);
-      *(float4 *)(P.dE + pos * 4) = d4;
-    } else {
-      for (int h = 0; h < H; ++h) P.dE[pos * H + h] = ((const float *)&raw[(size_t)p * H + h])[2];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    const int p = j * DGNN_WAVE + lane;
+    if (p < cnt) {
+      const size_t pos = (size_t)P.permute[e0 + p];
+      if (HC == 4) {
+        *(float4 *)(P.dE + pos * 4) = make_float4(cell[(size_t)p * HC + 0].y, cell[(size_t)p * HC + 1 % HC].y,
+                                                  cell[(size_t)p * HC + 2 % HC].y, cell[(size_t)p * HC + 3 % HC].y);
+      } else {
+#pragma unroll
+        for (int h = 0; h < HC; ++h) P.dE[pos * HC + h] = cell[(size_t)p * HC + h].y;
+      }
     }
   }
 }

@@ -172,10 +172,99 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_bwd_col(
 }
 
 // grad_attn_row[r,h] = sum over the row's edges of dE[e,h]  (fused_backward_kernel :961-967).
-// One 16-lane group per row (H == 4: one float4 = one edge per lane and step, 256 B per group
-// and step); a row longer than DGNN_ROWSUM_LONG edges is finished by the whole block with a
-// fixed reduction tree, so the result is deterministic.
+// H == 4 fast path: a 16-lane group owns DGNN_ROWSUM_R consecutive rows and issues the first
+// two 256-byte steps of ALL of them before reducing (8 independent float4 loads in flight per
+// lane: the per-row work is tiny, so the kernel lives on memory-level parallelism); longer rows
+// continue in a loop.  Rows beyond DGNN_ROWSUM_LONG edges are finished by the whole block with a
+// fixed reduction tree.  Everything is a fixed-order sum: deterministic.
 #define DGNN_ROWSUM_LONG 4096
+#define DGNN_ROWSUM_R 4
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4(int m, const int *__restrict__ row_ptr,
+                                                             const float4 *__restrict__ d4,
+                                                             float4 *__restrict__ grad_attn_row,
+                                                             int *__restrict__ long_count,
+                                                             int *__restrict__ long_list) {
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
+  const int rows_per_block = 16 * DGNN_ROWSUM_R;
+  const int rg = blockIdx.x * rows_per_block + grp * DGNN_ROWSUM_R;
+  // lanes 0..R of the group fetch the R+1 row pointers, then everybody reads them by shuffle
+  int myptr = 0;
+  if (q <= DGNN_ROWSUM_R && rg + q <= m) myptr = row_ptr[rg + q];
+  int lb[DGNN_ROWSUM_R], hb[DGNN_ROWSUM_R];
+  bool skip[DGNN_ROWSUM_R];
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v0[DGNN_ROWSUM_R], v1[DGNN_ROWSUM_R];
+#pragma unroll
+  for (int i = 0; i < DGNN_ROWSUM_R; ++i) {
+    lb[i] = __shfl(myptr, i, 16);
+    hb[i] = __shfl(myptr, i + 1, 16);
+    skip[i] = rg + i >= m;
+    if (skip[i]) { lb[i] = 0; hb[i] = 0; }
+    if (hb[i] - lb[i] > DGNN_ROWSUM_LONG) {
+      // hub row: queued for k_gat_row_sum4_long (one whole block per hub row).  The queue order
+      // varies from run to run, the value written for each row does not.
+      if (q == 0) long_list[atomicAdd(long_count, 1)] = rg + i;
+      skip[i] = true;
+      hb[i] = lb[i];
+    }
+    v0[i] = (lb[i] + q < hb[i]) ? d4[lb[i] + q] : z;
+    v1[i] = (lb[i] + q + 16 < hb[i]) ? d4[lb[i] + q + 16] : z;
+  }
+#pragma unroll
+  for (int i = 0; i < DGNN_ROWSUM_R; ++i) {
+    float4 s = make_float4(v0[i].x + v1[i].x, v0[i].y + v1[i].y, v0[i].z + v1[i].z, v0[i].w + v1[i].w);
+    for (int p = lb[i] + q + 32; p < hb[i]; p += 32) {
+      const float4 a = d4[p];
+      const float4 c = (p + 16 < hb[i]) ? d4[p + 16] : z;
+      s.x += a.x + c.x; s.y += a.y + c.y; s.z += a.z + c.z; s.w += a.w + c.w;
+    }
+    s.x = row16_reduce(s.x, OpSum());
+    s.y = row16_reduce(s.y, OpSum());
+    s.z = row16_reduce(s.z, OpSum());
+    s.w = row16_reduce(s.w, OpSum());
+    if (q == 0 && !skip[i]) grad_attn_row[rg + i] = s;
+  }
+}
+
+// One block per queued hub row: 256 threads, 4 independent float4 loads per step, fixed LDS
+// tree.  The grid is sized for the worst case (nnz / DGNN_ROWSUM_LONG rows); spare blocks exit.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4_long(const int *__restrict__ row_ptr,
+                                                                  const float4 *__restrict__ d4,
+                                                                  float4 *__restrict__ grad_attn_row,
+                                                                  const int *__restrict__ long_count,
+                                                                  const int *__restrict__ long_list) {
+  __shared__ float4 red[DGNN_BLOCK];
+  if ((int)blockIdx.x >= *long_count) return;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int rr = long_list[blockIdx.x];
+  const int l = row_ptr[rr], h2 = row_ptr[rr + 1];
+  float4 s0 = z, s1 = z, s2 = z, s3 = z;
+  for (int p = l + (int)threadIdx.x; p < h2; p += 4 * DGNN_BLOCK) {
+    const float4 a0 = d4[p];
+    const float4 a1 = (p + DGNN_BLOCK < h2) ? d4[p + DGNN_BLOCK] : z;
+    const float4 a2 = (p + 2 * DGNN_BLOCK < h2) ? d4[p + 2 * DGNN_BLOCK] : z;
+    const float4 a3 = (p + 3 * DGNN_BLOCK < h2) ? d4[p + 3 * DGNN_BLOCK] : z;
+    s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+    s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+    s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+    s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+  }
+  red[threadIdx.x] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                                 (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  for (int st = DGNN_BLOCK / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      const float4 o = red[threadIdx.x + st];
+      float4 mine = red[threadIdx.x];
+      mine.x += o.x; mine.y += o.y; mine.z += o.z; mine.w += o.w;
+      red[threadIdx.x] = mine;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) grad_attn_row[rr] = red[0];
+}
+
+// Any H: one 16-lane group per row.
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,
                                                             const int *__restrict__ row_ptr,
                                                             const float *__restrict__ dE,
@@ -191,26 +280,6 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,
     const int lb = row_ptr[r], hb = row_ptr[r + 1];
     if (hb - lb > DGNN_ROWSUM_LONG) {
       if (q == 0) any_long = 1;
-    } else if (H == 4 && (((uintptr_t)dE) & 15u) == 0) {
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 *d4 = (const float4 *)dE;
-      int p = lb + q;
-      for (; p + 48 < hb; p += 64) {   // 4 independent loads in flight per lane
-        const float4 v0 = d4[p], v1 = d4[p + 16], v2 = d4[p + 32], v3 = d4[p + 48];
-        s.x += (v0.x + v1.x) + (v2.x + v3.x);
-        s.y += (v0.y + v1.y) + (v2.y + v3.y);
-        s.z += (v0.z + v1.z) + (v2.z + v3.z);
-        s.w += (v0.w + v1.w) + (v2.w + v3.w);
-      }
-      for (; p < hb; p += 16) {
-        const float4 v = d4[p];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-      s.x = row16_reduce(s.x, OpSum());
-      s.y = row16_reduce(s.y, OpSum());
-      s.z = row16_reduce(s.z, OpSum());
-      s.w = row16_reduce(s.w, OpSum());
-      if (q == 0) *(float4 *)(grad_attn_row + (size_t)r * 4) = s;
     } else if (H <= 16 && (16 % H) == 0) {
       // the 16 lanes walk the row's contiguous [deg*H] slab; since 16 % H == 0 a lane
       // always lands on head q % H

@@ -65,7 +65,8 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
     DGNN_LAUNCH_CHECK();
   }
   if (P.T == 0) return DGNN_OK;
-  const size_t lds = fast_lds_bytes(P.H, P.L);
+  // DGNN_FWD_LDS_PAD: extra dynamic LDS per workgroup = an occupancy limiter for tuning runs
+  const size_t lds = fast_lds_bytes(P.H, P.L) + (size_t)env_int("DGNN_FWD_LDS_PAD", 0);
   const dim3 grid(blocks_for_waves(P.T));
   if (vec4)
     hipLaunchKernelGGL((k_fast_row_gather<MODE, 4>), grid, dim3(DGNN_BLOCK), lds, st, P);
@@ -108,12 +109,13 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
 struct BwdLayout {
   bool fast;
   int L, T, slot_stride;
-  size_t off_S, off_dE, off_stat, off_cols, off_slots, off_out, off_fwd, total;
+  size_t off_S, off_dE, off_long, off_stat, off_cols, off_slots, off_out, off_fwd, total;
+  int max_long;
 };
 
 bool bwd_fast_shape(int m, int n, int h, int f) {
-  return !force_generic() && h <= DGNN_FAST_HMAX && (f % 4 == 0) && (h * f <= 256) &&
-         is_pow2(f / 4) && m < (1 << 30) && n < (1 << 30);
+  return !force_generic() && (h == 1 || h == 2 || h == 4 || h == 8) && (f % 4 == 0) &&
+         (h * f <= 256) && is_pow2(f / 4) && m < (1 << 30) && n < (1 << 30);
 }
 
 BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
@@ -124,6 +126,9 @@ BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
   o += align_up(sizeof(float) * (size_t)m * h, 256);
   w.off_dE = o;
   o += align_up(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1) * h, 256);
+  w.max_long = nnz / DGNN_ROWSUM_LONG + 1;       // rows with more than DGNN_ROWSUM_LONG edges
+  w.off_long = o;                                // [0] = counter, [1..] = queue
+  o += align_up(sizeof(int) * ((size_t)w.max_long + 1), 256);
   if (w.fast) {
     w.L = bwd_group_size(h);
     w.T = (nnz + w.L - 1) / w.L;
@@ -255,7 +260,7 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     out = tmp;
   }
   bool fast = w.fast && aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
-              (out == nullptr || aligned16(out));
+              aligned16(attn_col) && (out == nullptr || aligned16(out));
   if (fast) {
     BwdParams P = {};
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
@@ -280,8 +285,16 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
       DGNN_LAUNCH_CHECK();
     }
     if (P.T > 0) {
-      hipLaunchKernelGGL(k_bwd_col_gather, dim3(blocks_for_waves(P.T)), dim3(DGNN_BLOCK),
-                         bwd_lds_bytes(h, P.L), st, P);
+      const dim3 grid(blocks_for_waves(P.T)), block(DGNN_BLOCK);
+      const size_t lds = bwd_lds_bytes(h, P.L) + (size_t)env_int("DGNN_BWD_LDS_PAD", 0);
+#define DGNN_BWD_CASE(HC, EPL)                                                              \
+  if (h == HC && P.L == 64 * EPL)                                                           \
+    hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL>), grid, block, lds, st, P);
+      DGNN_BWD_CASE(1, 1) DGNN_BWD_CASE(1, 2) DGNN_BWD_CASE(1, 4)
+      DGNN_BWD_CASE(2, 1) DGNN_BWD_CASE(2, 2) DGNN_BWD_CASE(2, 4)
+      DGNN_BWD_CASE(4, 1) DGNN_BWD_CASE(4, 2) DGNN_BWD_CASE(4, 4)
+      DGNN_BWD_CASE(8, 1) DGNN_BWD_CASE(8, 2)
+#undef DGNN_BWD_CASE
       DGNN_LAUNCH_CHECK();
       if (P.T > 1) {
         hipLaunchKernelGGL(k_bwd_fixup, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
@@ -304,8 +317,22 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     }
   }
   if (m > 0) {
-    hipLaunchKernelGGL(k_gat_row_sum, dim3((m + 15) / 16), dim3(DGNN_BLOCK), 0, st, m, h, row_ptr,
-                       dE, grad_attn_row);
+    if (h == 4 && aligned16(dE) && aligned16(grad_attn_row)) {
+      const int rows_per_block = 16 * DGNN_ROWSUM_R;
+      int *long_count = (int *)(ws + w.off_long);
+      hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int), st);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(k_gat_row_sum4, dim3((m + rows_per_block - 1) / rows_per_block),
+                         dim3(DGNN_BLOCK), 0, st, m, row_ptr, (const float4 *)dE,
+                         (float4 *)grad_attn_row, long_count, long_count + 1);
+      DGNN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_gat_row_sum4_long, dim3(w.max_long), dim3(DGNN_BLOCK), 0, st, row_ptr,
+                         (const float4 *)dE, (float4 *)grad_attn_row, (const int *)long_count,
+                         (const int *)(long_count + 1));
+    } else {
+      hipLaunchKernelGGL(k_gat_row_sum, dim3((m + 15) / 16), dim3(DGNN_BLOCK), 0, st, m, h, row_ptr,
+                         dE, grad_attn_row);
+    }
     DGNN_LAUNCH_CHECK();
   }
   return DGNN_OK;

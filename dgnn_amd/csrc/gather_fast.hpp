@@ -21,12 +21,14 @@
 //   * a tiny fix-up kernel merges the partial slots of cut rows in a fixed order (online
 //              softmax merge), so results are deterministic.
 #pragma once
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace dgnn {
 
 #ifndef DGNN_FAST_U
-#define DGNN_FAST_U 8          // feature-row gathers in flight per wave
+#define DGNN_FAST_U 3          // feature-row gathers in flight per wave (swept on MI355X: 1..16)
 #endif
 #define DGNN_FAST_HMAX 8
 #define DGNN_ROWEND 0x80000000u
@@ -51,7 +53,16 @@ struct GatherParams {
   float *slots;                      // [2T][slot_stride]
 };
 
-static inline int fast_group_size(int H) { return H <= 4 ? 256 : 128; }
+static inline int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e != nullptr && e[0] != 0) ? atoi(e) : dflt;
+}
+// Tuning override (multiples of 64): DGNN_FWD_L.
+static inline int fast_group_size(int H) {
+  const int dflt = H <= 4 ? 512 : 256;
+  const int v = env_int("DGNN_FWD_L", dflt);
+  return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : dflt;
+}
 static inline size_t fast_lds_bytes(int H, int L) {
   // per wave: weights [L*H] + column ids [L] + flush queue [L]
   return (size_t)DGNN_WAVES_PER_BLOCK * (size_t)L * (H + 2) * sizeof(float);
