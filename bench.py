@@ -23,6 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DGNN_TIMING", "1")     # event-time the dominant kernels (include/dgnn_hip.h)
 
 WORKLOADS = {
     # name: (nodes, unique directed edges incl. self loops, rmat scale)   SURVEY.md section 8(d)
@@ -96,6 +97,24 @@ def algorithmic_bytes(n, nnz, h, f):
     bwd_csc = nnz * (4 * hf + 16 * h + 8 + 4 * h) + n * (8 * hf + 8 * h + 4)
     total_model = nnz * (12 * hf + 28 * h + 12) + n * (12 * hf + 36 * h + 8)  # BASELINE.md formula
     return dict(fwd=fwd, bwd_csc=bwd_csc, survey_total=total_model)
+
+
+def measured_traffic(workload, which):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*pmc*: FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  None when no
+    profile of this workload is committed: counters cannot be read from inside the process."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_hbm_bytes_{workload}*.csv")))
+    if not files:
+        return None
+    key = "k_bwd_col_gather" if which == "bwd" else "k_fast_row_gather"
+    total = 0.0
+    for row in csv.DictReader(open(files[-1])):
+        if key in row["kernel"]:
+            total += float(row["avg_bytes_corrected"])
+    return total or None
 
 
 def cpu_baseline(name, seed=0):
@@ -191,13 +210,16 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
-    # Per-phase timing with events on the launch stream (torch's current stream), single GPU:
-    # the forward call and the backward call each are dominated by one gather kernel.
+    # Dominant-kernel timing, live: with DGNN_TIMING=1 the library brackets its forward
+    # row-gather kernel and its backward column-gather kernel with HIP events on the stream it
+    # launches on (dgnn_debug_last_kernel_ms); the whole forward / backward calls are also timed
+    # with events on the same (torch current) stream.
     roof = None
     if world == 1 and not args.force_dist:
+        from dgnn_amd import _lib
         from dgnn_amd.native import fused_gatconv
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        tf = tb = 0.0
+        tf = tb = kf = kb = 0.0
         reps = max(3, min(args.steps, 10))
         xd, ard, acd = in_feat.detach(), attn_row.detach(), attn_col.detach()
         for _ in range(reps):
@@ -210,19 +232,24 @@ def main():
             torch.cuda.synchronize()
             tf += ev[0].elapsed_time(ev[1])
             tb += ev[1].elapsed_time(ev[2])
-        tf /= reps
-        tb /= reps
+            kf += _lib.last_kernel_ms(0) or 0.0
+            kb += _lib.last_kernel_ms(1) or 0.0
+        tf, tb, kf, kb = tf / reps, tb / reps, kf / reps, kb / reps
         ab = algorithmic_bytes(n, nnz, H, F)
-        dom = ("gat_backward (CSC gather pass)", ab["bwd_csc"], tb) if tb >= tf else \
-              ("gat_forward (CSR gather pass)", ab["fwd"], tf)
+        if kf > 0 and kb > 0:
+            dom = ("k_bwd_col_gather (backward, one CSC gather pass)", ab["bwd_csc"], kb, "bwd") if kb >= kf else \
+                  ("k_fast_row_gather (forward, CSR gather pass)", ab["fwd"], kf, "fwd")
+        else:   # generic kernels in use: fall back to the call-level times
+            dom = ("gat_backward call", ab["bwd_csc"], tb, "bwd") if tb >= tf else ("gat_forward call", ab["fwd"], tf, "fwd")
         achieved = dom[1] / (dom[2] * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom[0],
-                "algorithmic_bytes": dom[1], "ms": round(dom[2], 3),
-                "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
-                "fwd_GBps": round(ab["fwd"] / (tf * 1e-3) / 1e9, 1),
-                "bwd_GBps": round(ab["bwd_csc"] / (tb * 1e-3) / 1e9, 1),
-                "survey_model_GBps": round(ab["survey_total"] / (ms_per_step * 1e-3) / 1e9, 1)}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom[3]),
+                "kernel": dom[0], "algorithmic_bytes": dom[1], "kernel_ms": round(dom[2], 3),
+                "fwd_kernel_ms": round(kf, 3), "bwd_kernel_ms": round(kb, 3),
+                "fwd_call_ms": round(tf, 3), "bwd_call_ms": round(tb, 3),
+                "fwd_kernel_GBps": round(ab["fwd"] / (kf * 1e-3) / 1e9, 1) if kf > 0 else None,
+                "bwd_kernel_GBps": round(ab["bwd_csc"] / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
+                "survey_3gather_model_GBps": round(ab["survey_total"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
     if rank == 0:
         line = {

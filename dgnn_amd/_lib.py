@@ -23,6 +23,7 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     "dgnn_abi_version": (_i, []),
     "dgnn_error_string": (ctypes.c_char_p, [_i]),
+    "dgnn_debug_last_kernel_ms": (_i, [_i, _vp]),
     "dgnn_gat_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_gat_forward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp, _sz, _vp]),
     "dgnn_gat_inference": (_i, [_i, _i, _i, _i, _f] + [_vp] * 6 + [_vp, _sz, _vp]),
@@ -117,3 +118,11 @@ def workspace(nbytes, like):
     if nbytes == 0:
         return None
     return torch.empty(int(nbytes), dtype=torch.uint8, device=like.device)
+
+
+def last_kernel_ms(which):
+    """Duration (ms) of the most recent dominant-kernel launch (0 = forward gather, 1 = backward
+    gather); needs DGNN_TIMING=1 in the environment before the library is loaded.  None if off."""
+    ms = ctypes.c_float(0.0)
+    rc = lib().dgnn_debug_last_kernel_ms(int(which), ctypes.byref(ms))
+    return float(ms.value) if rc == 0 else None

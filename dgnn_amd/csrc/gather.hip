@@ -22,6 +22,33 @@ inline bool force_generic() {
   return e != nullptr && e[0] == '1';
 }
 
+// Optional timing of the two dominant kernels (DGNN_TIMING=1): HIP events recorded on the launch
+// stream right around the kernel, read back with dgnn_debug_last_kernel_ms().  Off by default;
+// this is the only process-global state in the library and it never changes results.
+struct KernelTimer {
+  bool on = false, init = false;
+  hipEvent_t ev[2][2];
+  bool valid[2] = {false, false};
+};
+KernelTimer g_timer;
+inline bool timing_on() {
+  if (!g_timer.init) {
+    g_timer.init = true;
+    g_timer.on = env_int("DGNN_TIMING", 0) != 0;
+    if (g_timer.on)
+      for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 2; ++i)
+          if (hipEventCreate(&g_timer.ev[k][i]) != hipSuccess) g_timer.on = false;
+  }
+  return g_timer.on;
+}
+inline void timer_mark(int which, int edge, hipStream_t st) {
+  if (timing_on()) {
+    (void)hipEventRecord(g_timer.ev[which][edge], st);
+    if (edge == 1) g_timer.valid[which] = true;
+  }
+}
+
 // ----------------------------------------------------------------------------- forward side
 struct FwdLayout {
   int L, T, slot_stride;
@@ -68,10 +95,12 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   // DGNN_FWD_LDS_PAD: extra dynamic LDS per workgroup = an occupancy limiter for tuning runs
   const size_t lds = fast_lds_bytes(P.H, P.L) + (size_t)env_int("DGNN_FWD_LDS_PAD", 0);
   const dim3 grid(blocks_for_waves(P.T));
+  if (MODE == MODE_GAT) timer_mark(0, 0, st);
   if (vec4)
     hipLaunchKernelGGL((k_fast_row_gather<MODE, 4>), grid, dim3(DGNN_BLOCK), lds, st, P);
   else
     hipLaunchKernelGGL((k_fast_row_gather<MODE, 1>), grid, dim3(DGNN_BLOCK), lds, st, P);
+  if (MODE == MODE_GAT) timer_mark(0, 1, st);
   DGNN_LAUNCH_CHECK();
   if (P.T > 1) {
     hipLaunchKernelGGL(k_fast_fixup<MODE>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
@@ -157,6 +186,15 @@ int check_dims(int m, int nnz, int h, int f) {
 }  // namespace
 
 extern "C" {
+
+int dgnn_debug_last_kernel_ms(int which, float *ms) {
+  if (which < 0 || which > 1 || !ms) return DGNN_ERR_BAD_ARG;
+  if (!timing_on() || !g_timer.valid[which]) return DGNN_ERR_UNSUPPORTED;
+  hipError_t e = hipEventSynchronize(g_timer.ev[which][1]);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventElapsedTime(ms, g_timer.ev[which][0], g_timer.ev[which][1]);
+  return e == hipSuccess ? DGNN_OK : (int)e;
+}
 
 size_t dgnn_gat_forward_workspace_bytes(int m, int nnz, int h, int f) {
   if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
@@ -290,11 +328,13 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
 #define DGNN_BWD_CASE(HC, EPL)                                                              \
   if (h == HC && P.L == 64 * EPL)                                                           \
     hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL>), grid, block, lds, st, P);
+      timer_mark(1, 0, st);
       DGNN_BWD_CASE(1, 1) DGNN_BWD_CASE(1, 2) DGNN_BWD_CASE(1, 4)
       DGNN_BWD_CASE(2, 1) DGNN_BWD_CASE(2, 2) DGNN_BWD_CASE(2, 4)
       DGNN_BWD_CASE(4, 1) DGNN_BWD_CASE(4, 2) DGNN_BWD_CASE(4, 4)
       DGNN_BWD_CASE(8, 1) DGNN_BWD_CASE(8, 2)
 #undef DGNN_BWD_CASE
+      timer_mark(1, 1, st);
       DGNN_LAUNCH_CHECK();
       if (P.T > 1) {
         hipLaunchKernelGGL(k_bwd_fixup, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);

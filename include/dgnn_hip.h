@@ -40,6 +40,14 @@ extern "C" {
 int dgnn_abi_version(void);
 const char *dgnn_error_string(int code);
 
+/* Measurement aid, no counterpart in the reference.  With DGNN_TIMING=1 in the environment
+ * the library records HIP events on the launch stream right around its two dominant kernels
+ * (which = 0: forward row-gather kernel of dgnn_gat_forward / dgnn_gat_inference; which = 1:
+ * backward column-gather kernel of dgnn_gat_backward).  This returns the duration of the most
+ * recent such launch in milliseconds (it waits for that launch).  DGNN_ERR_UNSUPPORTED when
+ * timing is off or nothing was launched yet. */
+int dgnn_debug_last_kernel_ms(int which, float *ms);
+
 /* ------------------------------------------------------------------ fused GAT ---- */
 
 /* Scratch for dgnn_gat_forward / dgnn_gat_inference (neighbour-group partials). */
