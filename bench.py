@@ -259,7 +259,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
                                    f"attn_drop=0, fused GATConvFuse fwd+bwd",
-                       "parallelism": "single GPU" if world == 1 else f"row-partition x{world}, RCCL all-gather"},
+                       "parallelism": "single GPU" if world == 1 else
+                       f"row-partition x{world}, RCCL {os.environ.get('DGNN_DIST_MODE', 'halo')} exchange of boundary rows"},
         }
         if roof is not None:
             line["roofline"] = roof

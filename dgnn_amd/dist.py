@@ -7,20 +7,27 @@ The reference is single-GPU only; this is new d
   ``row_ptr`` prefix, not on node count: R-MAT ids are skewed, equal node ranges would give rank
   0 almost half of the edges);
 * rank p owns the destination rows AND the source columns of its node range:
-    forward   works on  A[lo:hi, :]  (its CSR rows, global column ids): it needs the source
-              features / source score terms of every node -> all-gather of the boundary-node
-              rows (``in_feat`` [N,H,F] and ``attn_col`` [N,H]);
-    backward  works on  A[:, lo:hi]  (its CSC columns, global row ids), one gather pass as on a
-              single GPU: it needs ``grad_out`` rows and the packed per-row statistics
-              (attn_row, edge_max, edge_sum, row_dot) of every destination -> two all-gathers;
-              grad_feat / grad_attn_col come out local, grad_attn_row comes out as a partial
-              [N,H] per rank -> one all-reduce, sliced to the local range.
+    forward   works on  A[lo:hi, :]  (its CSR rows): it needs the features / score terms of the
+              BOUNDARY nodes = the distinct sources its rows reference;
+    backward  works on  A[:, lo:hi]  (its CSC columns), one gather pass as on a single GPU: it
+              needs ``grad_out`` rows and the packed per-row statistics (attn_row, edge_max,
+              edge_sum, row_dot) of the distinct destinations its columns reference;
+              grad_feat / grad_attn_col come out local, grad_attn_row comes out as partial sums
+              for those destinations and travels back to their owners.
 * every rank runs exactly the single-GPU kernels (C ABI of include/dgnn_hip.h) on its block:
-  the forward on an (n_loc x N) rectangle, the backward on an (N x n_loc) rectangle.
+  the forward on an (n_loc x n_halo) rectangle, the backward on an (n_halo x n_loc) rectangle.
 
-All-gathers are over UNEVEN row blocks.  With RCCL, ``dist.all_gather`` on views of the full
-buffer moves each block once to every peer over its own xGMI link (direct, not a ring of
-7 hops of the whole tensor); with gloo (CPU tests) a broadcast per rank is used.
+Exchange (``mode``):
+  "halo" (default)  only the rows a rank actually references move: index lists are exchanged
+                    once at set-up, every step is one ``all_to_all_single`` with split sizes per
+                    tensor (direct peer-to-peer over each pair's own xGMI link).  The received
+                    rows arrive ordered by owner rank = globally sorted by node id, so the
+                    receive buffer IS the compact feature table the kernels gather from (column
+                    ids are relabelled to it once at set-up): no scatter pass.  On the
+                    products-shaped R-MAT graph at 8 ranks a rank needs ~35 % of the remote rows.
+  "allgather"       every rank receives every row (``dist.all_gather`` on uneven row blocks).
+Set with ``DGNN_DIST_MODE``.  gloo (CPU tests) takes the same code path; CUDA tensors under a
+non-NCCL backend are staged through the host.
 """
 import os
 
@@ -65,6 +72,23 @@ class _NativeOps:
         return self._fmt.csr2csc_int(ptr, ind, n_cols=n_cols)
 
 
+class _Halo:
+    """Who needs which of my rows, and which rows I need, for one direction of the exchange."""
+
+    def __init__(self, owner, needed_ids):
+        """needed_ids: sorted unique GLOBAL node ids (int64) this rank references."""
+        self.n_needed = needed_ids.numel()
+        b = torch.tensor(owner.bounds, dtype=torch.int64, device=needed_ids.device)
+        cut = torch.searchsorted(needed_ids, b)                      # [world+1]
+        self.recv_counts = [int(c) for c in (cut[1:] - cut[:-1]).cpu()]
+        send_counts = owner._a2a_counts(self.recv_counts)
+        self.send_counts = send_counts
+        wanted = torch.empty(sum(send_counts), dtype=torch.int64, device=needed_ids.device)
+        owner._a2a(wanted, needed_ids, send_counts, self.recv_counts)   # ids the peers want from me
+        self.send_idx = (wanted - owner.lo).contiguous()                # local row indices, by peer
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < owner.n_loc)
+
+
 class PartitionedGAT:
     """Fused GAT forward+backward on rank ``rank``'s share of a row-partitioned graph.
 
@@ -74,40 +98,101 @@ class PartitionedGAT:
     collectives without a GPU.
     """
 
-    def __init__(self, graph, world, rank, device, ops=None, group=None):
+    def __init__(self, graph, world, rank, device, ops=None, group=None, mode=None):
         self.world, self.rank, self.device, self.group = world, rank, device, group
         self.ops = ops if ops is not None else _NativeOps()
+        self.mode = mode or os.environ.get("DGNN_DIST_MODE", "halo")
+        if self.mode not in ("halo", "allgather"):
+            raise ValueError(f"unknown exchange mode {self.mode!r}")
         row_ptr, col_ind = graph["row_ptr"], graph["col_ind"]
         col_ptr, row_ind = graph["col_ptr"], graph["row_ind"]
         self.n = row_ptr.numel() - 1
         self.bounds = partition_bounds(row_ptr, world)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
         self.lo, self.hi, self.n_loc = lo, hi, hi - lo
-        # forward block  A[lo:hi, :]  (CSR, global column ids)
+        # forward block  A[lo:hi, :]  (CSR)
         e0, e1 = int(row_ptr[lo]), int(row_ptr[hi])
         self.f_row_ptr = (row_ptr[lo:hi + 1] - row_ptr[lo]).to(torch.int32).contiguous()
-        self.f_col_ind = col_ind[e0:e1].contiguous()
-        # backward block  A[:, lo:hi]  (CSC, global row ids) and its own CSR ordering
+        f_col = col_ind[e0:e1].contiguous()
+        # backward block  A[:, lo:hi]  (CSC)
         c0, c1 = int(col_ptr[lo]), int(col_ptr[hi])
         self.b_col_ptr = (col_ptr[lo:hi + 1] - col_ptr[lo]).to(torch.int32).contiguous()
-        self.b_row_ind = row_ind[c0:c1].contiguous()
-        b_row_ptr, b_col_ind, perm2 = self.ops.transpose(self.b_col_ptr, self.b_row_ind, self.n)
+        b_row = row_ind[c0:c1].contiguous()
+        self.nnz_fwd, self.nnz_bwd = e1 - e0, c1 - c0
+        if self.mode == "halo":
+            uf = torch.unique(f_col.long())                           # sorted distinct sources
+            self.f_col_ind = torch.searchsorted(uf, f_col.long()).to(torch.int32).contiguous()
+            self.f_halo = _Halo(self, uf)
+            ub = torch.unique(b_row.long())                           # sorted distinct destinations
+            self.b_row_ind = torch.searchsorted(ub, b_row.long()).to(torch.int32).contiguous()
+            self.b_halo = _Halo(self, ub)
+            n_rows_b = ub.numel()
+        else:
+            self.f_col_ind, self.b_row_ind, n_rows_b = f_col, b_row, self.n
+        # the backward block's own CSR ordering (for the per-row sum of the edge gradients)
+        b_row_ptr, b_col_ind, perm2 = self.ops.transpose(self.b_col_ptr, self.b_row_ind, n_rows_b)
         self.b_row_ptr, self.b_col_ind = b_row_ptr, b_col_ind
         # perm2[j] = CSC position of the block's CSR entry j; the kernels want the inverse
         inv = torch.empty_like(perm2)
         inv[perm2.long()] = torch.arange(perm2.numel(), dtype=perm2.dtype, device=perm2.device)
         self.b_permute = inv
-        self.nnz_fwd, self.nnz_bwd = e1 - e0, c1 - c0
         self._ctx = None
 
     # ------------------------------------------------------------------ collectives
-    def _all_gather_rows(self, local, full):
+    def _nccl(self):
+        return self.world > 1 and dist.get_backend(self.group) == "nccl"
+
+    def _a2a_counts(self, counts):
+        if self.world == 1:
+            return list(counts)
+        dev = self.device if self._nccl() else torch.device("cpu")
+        inp = torch.tensor(counts, dtype=torch.int64, device=dev)
+        out = torch.empty_like(inp)
+        dist.all_to_all_single(out, inp, group=self.group)
+        return [int(c) for c in out.cpu()]
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        """out (rows grouped by source rank) <- inp (rows grouped by destination rank)."""
+        if self.world == 1:
+            out.copy_(inp)
+            return out
+        if self._nccl() or not inp.is_cuda:
+            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
+        else:                                   # e.g. gloo with device tensors: stage through the host
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.contiguous().cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        return out
+
+    def _fetch(self, halo, local):
+        """Rows of every peer that this rank references (plus its own), in node-id order."""
+        send = local.index_select(0, halo.send_idx)
+        table = torch.empty((halo.n_needed,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        return self._a2a(table, send, halo.recv_counts, halo.send_counts)
+
+    def _return_rows(self, halo, partial):
+        """Inverse of _fetch for additive results: partial [n_needed,...] rows go back to their
+        owners and are summed there in a fixed (peer) order."""
+        back = torch.empty((halo.send_idx.numel(),) + tuple(partial.shape[1:]), dtype=partial.dtype,
+                           device=partial.device)
+        self._a2a(back, partial, halo.send_counts, halo.recv_counts)
+        acc = torch.zeros((self.n_loc,) + tuple(partial.shape[1:]), dtype=partial.dtype, device=partial.device)
+        off = 0
+        for cnt in halo.send_counts:              # ids are distinct inside one peer's list
+            if cnt:
+                idx = halo.send_idx[off:off + cnt]
+                acc[idx] += back[off:off + cnt]
+            off += cnt
+        return acc
+
+    def _all_gather_rows(self, local):
         """full[bounds[q]:bounds[q+1]] <- rank q's ``local`` rows, for every q."""
+        full = torch.empty((self.n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         if self.world == 1:
             full.copy_(local)
             return full
         views = [full[self.bounds[q]:self.bounds[q + 1]] for q in range(self.world)]
-        if dist.get_backend(self.group) == "nccl" and os.environ.get("DGNN_DIST_GATHER", "allgather") != "broadcast":
+        if self._nccl() and os.environ.get("DGNN_DIST_GATHER", "allgather") != "broadcast":
             dist.all_gather(views, local.contiguous(), group=self.group)   # uneven blocks: grouped sends
         else:
             for q in range(self.world):
@@ -116,16 +201,19 @@ class PartitionedGAT:
                 dist.broadcast(views[q], src=q, group=self.group)
         return full
 
-    def _full(self, local):
-        return torch.empty((self.n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    def _rows_for_forward(self, local):
+        return self._fetch(self.f_halo, local) if self.mode == "halo" else self._all_gather_rows(local)
+
+    def _rows_for_backward(self, local):
+        return self._fetch(self.b_halo, local) if self.mode == "halo" else self._all_gather_rows(local)
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, in_feat_loc, attn_row_loc, attn_col_loc, slope):
         """Local rows of GATConvFuse(...): [n_loc,H,F]."""
-        in_full = self._all_gather_rows(in_feat_loc, self._full(in_feat_loc))
-        ac_full = self._all_gather_rows(attn_col_loc, self._full(attn_col_loc))
-        out, emax, esum = self.ops.gat_forward(attn_row_loc.contiguous(), ac_full, self.f_row_ptr,
-                                               self.f_col_ind, slope, in_full)
+        in_tab = self._rows_for_forward(in_feat_loc.contiguous())
+        ac_tab = self._rows_for_forward(attn_col_loc.contiguous())
+        out, emax, esum = self.ops.gat_forward(attn_row_loc.contiguous(), ac_tab, self.f_row_ptr,
+                                               self.f_col_ind, slope, in_tab)
         self._ctx = (in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope)
         return out
 
@@ -133,18 +221,21 @@ class PartitionedGAT:
         """-> (grad_feat_loc [n_loc,H,F], grad_attn_row_loc [n_loc,H], grad_attn_col_loc [n_loc,H])."""
         in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope = self._ctx
         grad_out_loc = grad_out_loc.contiguous()
-        grad_full = self._all_gather_rows(grad_out_loc, self._full(grad_out_loc))
+        grad_tab = self._rows_for_backward(grad_out_loc)
         S_loc = self.ops.row_dot(grad_out_loc, out)
-        stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=1)          # [n_loc,4,H]
-        stat_full = self._all_gather_rows(stat_loc, self._full(stat_loc))
-        stat = stat_full.permute(1, 0, 2).contiguous()                            # [4,N,H]
+        stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=1).contiguous()   # [n_loc,4,H]
+        stat = self._rows_for_backward(stat_loc).permute(1, 0, 2).contiguous()          # [4,rows,H]
         gf, gr_partial, gc = self.ops.gat_backward(
             slope, self.b_row_ptr, self.b_col_ind, self.b_col_ptr, self.b_row_ind, self.b_permute,
-            stat[1], stat[2], in_feat_loc.contiguous(), stat[0], attn_col_loc.contiguous(), grad_full,
+            stat[1], stat[2], in_feat_loc.contiguous(), stat[0], attn_col_loc.contiguous(), grad_tab,
             stat[3])
-        if self.world > 1:
-            dist.all_reduce(gr_partial, group=self.group)
-        return gf, gr_partial[self.lo:self.hi].contiguous(), gc
+        if self.mode == "halo":
+            gr = self._return_rows(self.b_halo, gr_partial)
+        else:
+            if self.world > 1:
+                dist.all_reduce(gr_partial, group=self.group)
+            gr = gr_partial[self.lo:self.hi].contiguous()
+        return gf, gr, gc
 
     def step(self, in_feat, attn_row, attn_col, grad_out, slope):
         """One forward+backward given FULL tensors (every rank slices its own range): the unit

@@ -27,11 +27,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(world, mode, spec, h, f):
+def run_world(world, mode, spec, h, f, exchange="halo"):
     port = free_port()
+    env = dict(os.environ, DGNN_DIST_MODE=exchange)
     with tempfile.TemporaryDirectory() as out_dir:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world),
-                                   mode, str(port), out_dir, ",".join(map(str, spec)), str(h), str(f)])
+                                   mode, str(port), out_dir, ",".join(map(str, spec)), str(h), str(f)], env=env)
                  for r in range(world)]
         try:
             for p in procs:
@@ -68,16 +69,17 @@ def check(parts, spec, h, f):
     assert_close(gc, gc64, "partitioned grad_attn_col", mass=m_gc)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_gat_cpu_gloo(world):
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "allgather"), (3, "allgather")])
+def test_partitioned_gat_cpu_gloo(world, exchange):
     spec, h, f = (10, 700, 6000, 5), 2, 8
-    check(run_world(world, "cpu", spec, h, f), spec, h, f)
+    check(run_world(world, "cpu", spec, h, f, exchange), spec, h, f)
 
 
 @pytest.mark.gpu
-def test_partitioned_gat_gpu_two_ranks():
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_partitioned_gat_gpu_two_ranks(exchange):
     spec, h, f = (12, 4000, 60000, 7), 4, 64
-    check(run_world(2, "gpu", spec, h, f), spec, h, f)
+    check(run_world(2, "gpu", spec, h, f, exchange), spec, h, f)
 
 
 def test_partition_bounds_balance_edges_not_nodes():
