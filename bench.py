@@ -166,7 +166,24 @@ def main():
     import dgnn_amd  # noqa: F401
     from dgnn_amd.operators import GATConvFuse
 
-    g = build_graph(args.workload, device, seed=0)
+    if world > 1:
+        # one graph for everybody: rank 0 builds it, the index arrays are broadcast over RCCL
+        import torch.distributed as dist
+        g = build_graph(args.workload, device, seed=0) if rank == 0 else None
+        meta = torch.tensor([g["n"], g["nnz"]] if rank == 0 else [0, 0], dtype=torch.int64, device=device)
+        dist.broadcast(meta, src=0)
+        n, nnz = int(meta[0]), int(meta[1])
+        if rank != 0:
+            g = dict(n=n, nnz=nnz,
+                     row_ptr=torch.empty(n + 1, dtype=torch.int32, device=device),
+                     col_ind=torch.empty(nnz, dtype=torch.int32, device=device),
+                     col_ptr=torch.empty(n + 1, dtype=torch.int32, device=device),
+                     row_ind=torch.empty(nnz, dtype=torch.int32, device=device),
+                     permute=torch.empty(nnz, dtype=torch.int32, device=device))
+        for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute"):
+            dist.broadcast(g[k], src=0)
+    else:
+        g = build_graph(args.workload, device, seed=0)
     n, nnz = g["n"], g["nnz"]
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
