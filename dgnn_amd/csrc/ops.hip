@@ -1,5 +1,7 @@
 // Multi-head SDDMM, edge permute, Gaussian kernels and fused EdgeConv:
 // kernels + C-ABI entry points (include/dgnn_hip.h).
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace dgnn;
@@ -31,6 +33,124 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_row(int v, int H, int F,
       if (lane == 0) out[(size_t)p * H + h] = s;
     }
   }
+}
+
+// Neighbour-grouped SDDMM (fast path): one wave64 per group of DGNN_SDDMM_L consecutive edges,
+// whatever rows it spans.  The row operand A[r] rides the same software-pipelined load stream
+// as the gathered B rows (a "U item" in front of the row's edges), each a fully coalesced
+// 16 B/lane load; the dot product reduces inside the F/4 lanes of a head with DPP row ops.
+// No binary search per edge (findRow, computeUtil.h:38-54): the group finds its first row once
+// with a 64-ary cooperative search.  Per-edge outputs are staged in LDS and stored coalesced.
+#define DGNN_SDDMM_L 256
+#define DGNN_SDDMM_U 4
+#define DGNN_SDDMM_UFLAG 0x80000000u
+__global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H, int F, int HF,
+                                                           int rowv, int fv,
+                                                           const int *__restrict__ row_ptr,
+                                                           const int *__restrict__ col_ind,
+                                                           const float *__restrict__ A,
+                                                           const float *__restrict__ B,
+                                                           float *__restrict__ out) {
+  extern __shared__ __align__(16) float lds_raw[];
+  constexpr int L = DGNN_SDDMM_L;
+  const int wib = wave_in_block();
+  const int lane = lane_id();
+  const int T = (nnz + L - 1) / L;
+  const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
+  if (t >= T) return;
+  const size_t per_wave = (size_t)L * 3 + (size_t)L * H;
+  unsigned *stream = (unsigned *)(lds_raw + (size_t)wib * per_wave);   // [2L]
+  int *kof = (int *)(stream + 2 * L);                                   // [L] row ordinal of edge p
+  float *dbuf = (float *)(kof + L);                                     // [L][H]
+  const int e0 = t * L;
+  const int e1 = min(e0 + L, nnz);
+  const int cnt = e1 - e0;
+
+  // first row of the group: largest r with row_ptr[r] <= e0 (64-ary search, ~4 rounds)
+  int lo = 0, hi = v;
+  while (hi - lo > 1) {
+    const int step = (hi - lo + DGNN_WAVE - 1) / DGNN_WAVE;
+    const long long idx = (long long)lo + (long long)(lane + 1) * step;
+    const bool ok = (idx < hi) && (row_ptr[idx] <= e0);
+    const int c = __popcll(__ballot(ok));
+    const int nlo = lo + c * step;
+    const long long nhi = (long long)lo + (long long)(c + 1) * step;
+    lo = nlo;
+    hi = (int)(nhi < hi ? nhi : hi);
+  }
+  // rows of the group, one lane per row
+  int K = 0;
+  {
+    int rbase = lo;
+    while (true) {
+      const int r = rbase + lane;
+      int rs = 0x7fffffff, re = 0x7fffffff;
+      if (r < v) {
+        rs = row_ptr[r];
+        re = row_ptr[r + 1];
+      }
+      const int a = max(rs, e0) - e0;
+      const int b = (re < e1 ? re : e1) - e0;
+      const bool nonempty = (r < v) && (rs < e1) && (b > a);
+      const unsigned long long bal = __ballot(nonempty);
+      const int k = K + __popcll(bal & ((1ull << lane) - 1ull));
+      if (nonempty) {
+        stream[a + k] = (unsigned)r | DGNN_SDDMM_UFLAG;
+        for (int p = a; p < b; ++p) kof[p] = k;
+      }
+      K += __popcll(bal);
+      const bool reached_end = (r >= v - 1) || (re >= e1);
+      if (__ballot(reached_end) != 0ull) break;
+      rbase += DGNN_WAVE;
+    }
+  }
+  wave_lds_sync();
+  for (int p = lane; p < cnt; p += DGNN_WAVE) stream[p + kof[p] + 1] = (unsigned)col_ind[e0 + p];
+  wave_lds_sync();
+
+  const bool active = lane < rowv;
+  const int head = active ? (lane * 4) / F : 0;
+  const size_t lane_off = (size_t)(active ? lane : 0) * 4;
+  const bool head_leader = active && (lane % fv) == 0;
+  const int items = cnt + K;
+  float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = -1;
+  float4 ring[DGNN_SDDMM_U];
+#pragma unroll
+  for (int i = 0; i < DGNN_SDDMM_U; ++i) {
+    ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < items) {
+      const unsigned sv = (unsigned)uniform_i32((int)stream[i]);
+      const float *base = (sv & DGNN_SDDMM_UFLAG) ? A : B;
+      if (active) ring[i] = *(const float4 *)(base + (size_t)(sv & 0x7fffffffu) * HF + lane_off);
+    }
+  }
+  for (int j = 0; j < items; j += DGNN_SDDMM_U) {
+#pragma unroll
+    for (int i = 0; i < DGNN_SDDMM_U; ++i) {
+      const int it = j + i;
+      if (it < items) {
+        const float4 x = ring[i];
+        const unsigned sv = (unsigned)uniform_i32((int)stream[it]);
+        if (it + DGNN_SDDMM_U < items) {
+          const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_SDDMM_U]);
+          const float *base = (nv & DGNN_SDDMM_UFLAG) ? A : B;
+          if (active) ring[i] = *(const float4 *)(base + (size_t)(nv & 0x7fffffffu) * HF + lane_off);
+        }
+        if (sv & DGNN_SDDMM_UFLAG) {
+          u = x;
+          ++k;
+        } else {
+          const int p = it - (k + 1);
+          float dot = fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
+          dot = group_reduce(dot, fv, OpSum());
+          if (head_leader) dbuf[(size_t)p * H + head] = dot;
+        }
+      }
+    }
+  }
+  wave_lds_sync();
+  for (int i = lane; i < cnt * H; i += DGNN_WAVE) out[(size_t)e0 * H + i] = dbuf[i];
 }
 
 // out[i,:] = in[permute[i],:]   (mhtranspose_kernel.cu:6-26)
@@ -214,8 +334,21 @@ int dgnn_mhsddmm(int v, int f, int h, int nnz, const int *row_ptr, const int *co
   if (v < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
   if (!row_ptr || (nnz > 0 && (!col_ind || !grad || !feature || !out))) return DGNN_ERR_BAD_ARG;
   if (v == 0 || nnz == 0) return DGNN_OK;
-  hipLaunchKernelGGL(k_sddmm_row, dim3(blocks_for_waves(v)), dim3(DGNN_BLOCK), 0,
-                     (hipStream_t)stream, v, h, f, row_ptr, col_ind, grad, feature, out);
+  const int hf = h * f;
+  const bool pow2 = (f % 4 == 0) && (((f / 4) & (f / 4 - 1)) == 0);
+  const char *fg = getenv("DGNN_FORCE_GENERIC");
+  const bool fast = pow2 && hf <= 256 && h <= 8 && v < (1 << 30) && !(fg && fg[0] == '1') &&
+                    (((uintptr_t)grad | (uintptr_t)feature) & 15u) == 0;
+  if (fast) {
+    const int T = (nnz + DGNN_SDDMM_L - 1) / DGNN_SDDMM_L;
+    const size_t lds = (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)DGNN_SDDMM_L * 3 + (size_t)DGNN_SDDMM_L * h) * sizeof(float);
+    hipLaunchKernelGGL(k_sddmm_fast, dim3(blocks_for_waves(T)), dim3(DGNN_BLOCK), lds,
+                       (hipStream_t)stream, v, nnz, h, f, hf, hf / 4, f / 4, row_ptr, col_ind, grad,
+                       feature, out);
+  } else {
+    hipLaunchKernelGGL(k_sddmm_row, dim3(blocks_for_waves(v)), dim3(DGNN_BLOCK), 0,
+                       (hipStream_t)stream, v, h, f, row_ptr, col_ind, grad, feature, out);
+  }
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

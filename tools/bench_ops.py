@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Secondary operator benchmarks on one GPU (BASELINE.json configs 2-4): fused EdgeConv on a
+ModelNet40-shaped batch, fused GMMConv on a PubMed-shaped graph, SpMM / SDDMM / GAT on a
+Reddit-shaped R-MAT.  Prints one JSON line per operator with algorithmic GB/s."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(iters):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / iters
+
+
+def edgeconv(batch=32, pts=2048, k=20):
+    from dgnn_amd.native import fused_edgeconv as fe
+    m = batch * pts
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    # k random neighbours inside each cloud (the k-NN graph itself is DGL's job in the reference)
+    base = (torch.arange(m, device=dev) // pts * pts)[:, None]
+    src = (base + torch.randint(0, pts, (m, k), device=dev, generator=gen)).to(torch.int32).reshape(-1).contiguous()
+    for f in (64, 64, 128, 256):
+        hs = torch.randn((m, f), device=dev, generator=gen)
+        hd = torch.randn((m, f), device=dev, generator=gen)
+        go = torch.randn((m, f), device=dev, generator=gen)
+        out, idx_f, idx_i = fe.edgeconv_forward(k, src, hs, hd, return_int_idx=True)
+        tf = timeit(lambda: fe.edgeconv_forward(k, src, hs, hd, return_int_idx=True))
+        tb = timeit(lambda: fe.edgeconv_backward(go, idx_i))
+        bf = m * (4 * k + 4 * k * f + 4 * f + 12 * f)
+        bb = m * (4 * f + 4 * f + 8 * f + 4 * f)
+        print(json.dumps({"op": "edgeconv", "m": m, "k": k, "f": f, "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4),
+                          "fwd_GBps": round(bf / tf / 1e6, 1), "bwd_GBps": round(bb / tb / 1e6, 1)}), flush=True)
+
+
+def gmm_pubmed():
+    from dgnn_amd.operators import GmmConvFuse
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import random_graph
+    g = random_graph(19717, 88648, 0)
+    G = {k2: torch.from_numpy(g[k2]).to(dev) for k2 in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")}
+    K, D, F = 3, 2, 64
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    x = torch.randn((g["n"], K, F), device=dev, generator=gen).requires_grad_()
+    ps = torch.rand((g["nnz"], D), device=dev, generator=gen).requires_grad_()
+    mu = (0.1 * torch.randn((K, D), device=dev, generator=gen)).requires_grad_()
+    sg = torch.ones((K, D), device=dev).requires_grad_()
+    go = torch.randn((g["n"], K, F), device=dev, generator=gen)
+
+    def step():
+        x.grad = ps.grad = mu.grad = sg.grad = None
+        GmmConvFuse(G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], x, ps, mu, sg).backward(go)
+    t = timeit(step, iters=50)
+    print(json.dumps({"op": "gmmconv fwd+bwd (PubMed-shaped)", "n": g["n"], "nnz": g["nnz"], "K": K, "D": D, "F": F,
+                      "ms": round(t, 4), "edges_per_s": round(g["nnz"] / t * 1e3)}), flush=True)
+
+
+def reddit():
+    from dgnn_amd.native import fused_gatconv as fg, mhsddmm, spmm
+    g = bench.build_graph("reddit", dev)
+    n, nnz = g["n"], g["nnz"]
+    H, F = 4, 64
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    x = torch.rand((n, H, F), device=dev, generator=gen) - 0.4
+    ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
+    ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
+    go = torch.rand((n, H, F), device=dev, generator=gen) - 0.5
+    val = torch.rand((nnz, H), device=dev, generator=gen)
+    out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
+    tf = timeit(lambda: fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0), iters=5, warm=2)
+    tb = timeit(lambda: fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"],
+                                        emax, esum, emask, x, ar, ac, go, out_feat=out), iters=5, warm=2)
+    ab = bench.algorithmic_bytes(n, nnz, H, F)
+    print(json.dumps({"op": "gat fwd+bwd (Reddit-shaped R-MAT)", "n": n, "nnz": nnz, "fwd_ms": round(tf, 3),
+                      "bwd_ms": round(tb, 3), "edges_per_s": round(nnz / (tf + tb) * 1e3),
+                      "fwd_GBps": round(ab["fwd"] / tf / 1e6, 1), "bwd_GBps": round(ab["bwd_csc"] / tb / 1e6, 1)}), flush=True)
+    ts = timeit(lambda: spmm.spmm_csr(g["row_ptr"], g["col_ind"], val, x), iters=5, warm=2)
+    td = timeit(lambda: mhsddmm.mhsddmm(g["row_ptr"], g["col_ind"], go, x), iters=3, warm=1)
+    print(json.dumps({"op": "spmm_csr (Reddit-shaped)", "ms": round(ts, 3),
+                      "GBps": round((nnz * (4 * H * F + 4 * H + 4) + n * 4 * H * F) / ts / 1e6, 1)}), flush=True)
+    print(json.dumps({"op": "mhsddmm (Reddit-shaped)", "ms": round(td, 3),
+                      "GBps": round((nnz * (4 * H * F + 4 * H + 4) + n * 4 * H * F) / td / 1e6, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["edgeconv", "gmm", "reddit"])
+    a = ap.parse_args()
+    for w in a.which:
+        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit}[w]()
