@@ -1,0 +1,189 @@
+"""Full-size checks of the fused GAT path at BASELINE.json's headline configuration
+(ogbn-products-shaped R-MAT: 2,449,029 nodes, 62 M edges, 4 heads x 64), where the oracle cannot
+run the whole graph in seconds:
+
+  * size-independent properties of the operator: rows of the attention matrix sum to one,
+    exact homogeneity under scaling by 2 (bit-exact, and with it run-to-run determinism: the
+    kernels use no float atomics), sum_r grad_attn_row == sum_c grad_attn_col (both are the sum
+    of the same per-edge terms), per-row statistics against a plain torch segment reduction;
+  * sampled rows / columns against the float64 oracle: the sub-problem that determines them
+    exactly (their complete rows, relabelled) is cut out of the big graph and handed to the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import assert_close, gat_masses
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+H, F, SLOPE = 4, 64, 0.2
+
+
+@pytest.fixture(scope="module")
+def big():
+    import bench
+    from dgnn_amd.native import fused_gatconv
+    dev = torch.device(DEV)
+    g = bench.build_graph("products", dev, seed=0)
+    n = g["n"]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    x = torch.rand((n, H, F), device=dev, generator=gen) - 0.4
+    ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
+    ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
+    grad = torch.rand((n, H, F), device=dev, generator=gen) - 0.5
+    out, emax, esum, emask = fused_gatconv.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], SLOPE, x, 0.0)
+    gf, gr, gc = fused_gatconv.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                                            g["permute"], emax, esum, emask, x, ar, ac, grad, out_feat=out)
+    torch.cuda.synchronize()
+    return dict(g=g, x=x, ar=ar, ac=ac, grad=grad, out=out, emax=emax, esum=esum, emask=emask,
+                gf=gf, gr=gr, gc=gc, ops=fused_gatconv)
+
+
+def test_graph_is_the_headline_shape(big):
+    g = big["g"]
+    assert g["n"] == 2_449_029 and g["nnz"] == 62_000_000
+    rp, ci = g["row_ptr"].long(), g["col_ind"].long()
+    assert int(rp[0]) == 0 and int(rp[-1]) == g["nnz"] and bool((rp[1:] >= rp[:-1]).all())
+    # strictly ascending columns inside each row (the reference's CSR convention): the key
+    # row*n+col is strictly increasing over the whole array
+    row = torch.repeat_interleave(torch.arange(g["n"], device=DEV), rp[1:] - rp[:-1])
+    key = row * g["n"] + ci
+    assert bool((key[1:] > key[:-1]).all())
+    # CSC + permute are the same matrix: entry i of the CSC is CSR entry permute[i]
+    pm = g["permute"].long()
+    assert bool((torch.sort(pm).values == torch.arange(g["nnz"], device=DEV)).all())
+    col_of_csc = torch.repeat_interleave(torch.arange(g["n"], device=DEV),
+                                         g["col_ptr"].long()[1:] - g["col_ptr"].long()[:-1])
+    assert bool((ci[pm] == col_of_csc).all()) and bool((row[pm] == g["row_ind"].long()).all())
+
+
+def test_row_statistics_match_a_torch_segment_reduction(big):
+    g = big["g"]
+    rp = g["row_ptr"].long()
+    row = torch.repeat_interleave(torch.arange(g["n"], device=DEV), rp[1:] - rp[:-1])
+    e = torch.nn.functional.leaky_relu(big["ar"][row] + big["ac"][g["col_ind"].long()], SLOPE)
+    emax = torch.full((g["n"], H), -1e38, device=DEV).scatter_reduce(
+        0, row[:, None].expand(-1, H), e, "amax", include_self=True)
+    assert torch.equal(emax, big["emax"]), "edge_max is a pure max: bit-exact"
+    esum = torch.zeros((g["n"], H), device=DEV, dtype=torch.float64).index_add_(
+        0, row, torch.exp((e - emax[row]).double()))
+    rel = ((big["esum"].double() - esum).abs() / esum).max().item()
+    assert rel <= 1e-5, rel
+
+
+def test_attention_rows_sum_to_one(big):
+    g = big["g"]
+    ones = torch.ones((g["n"], H, F), device=DEV)
+    out = big["ops"].gat_inference(big["ar"], big["ac"], g["row_ptr"], g["col_ind"], SLOPE, ones)
+    # every row has its self loop, so no row is empty
+    assert (out - 1.0).abs().max().item() <= 1e-5
+
+
+def test_scaling_by_two_is_bit_exact(big):
+    g, ops = big["g"], big["ops"]
+    out2, emax2, esum2, _ = ops.gat_forward(big["ar"], big["ac"], g["row_ptr"], g["col_ind"], SLOPE,
+                                            big["x"] * 2.0, 0.0)
+    assert torch.equal(out2, big["out"] * 2.0)
+    assert torch.equal(emax2, big["emax"]) and torch.equal(esum2, big["esum"])
+    # the backward is linear in grad for fixed inputs; S = <grad, out> scales with it
+    gf2, gr2, gc2 = ops.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                                     g["permute"], big["emax"], big["esum"], big["emask"], big["x"],
+                                     big["ar"], big["ac"], big["grad"] * 2.0, out_feat=big["out"])
+    assert torch.equal(gf2, big["gf"] * 2.0)
+    assert torch.equal(gr2, big["gr"] * 2.0) and torch.equal(gc2, big["gc"] * 2.0)
+
+
+def test_attention_gradients_sum_to_the_same_total(big):
+    # sum_r grad_attn_row[r,h] = sum_e d[e,h] = sum_c grad_attn_col[c,h]; each row's d sums to
+    # zero analytically before the LeakyReLU factor, so the totals are small against the mass
+    tr = big["gr"].double().sum(0)
+    tc = big["gc"].double().sum(0)
+    scale = big["gr"].double().abs().sum(0) + big["gc"].double().abs().sum(0)
+    assert bool(((tr - tc).abs() <= 1e-5 * scale).all()), (tr, tc, scale)
+
+
+def cut_rows(g, rows):
+    """Sub-problem holding the complete CSR rows `rows` (sorted unique, device int64) of g:
+    nodes = rows and every column they touch, relabelled in ascending order; the other nodes'
+    rows are empty.  Returns (nodes, graph dict of numpy arrays, local ids of `rows`)."""
+    import scipy.sparse as sp
+    rp = g["row_ptr"].long()
+    deg = rp[rows + 1] - rp[rows]
+    off = torch.cumsum(deg, 0) - deg
+    eidx = torch.repeat_interleave(rp[rows] - off, deg) + torch.arange(int(deg.sum()), device=rows.device)
+    cols = g["col_ind"].long()[eidx]
+    nodes = torch.unique(torch.cat([rows, cols]))
+    rows_l = torch.searchsorted(nodes, rows)
+    cols_l = torch.searchsorted(nodes, cols).cpu().numpy().astype(np.int32)
+    ns = int(nodes.numel())
+    deg_s = np.zeros(ns, np.int64)
+    deg_s[rows_l.cpu().numpy()] = deg.cpu().numpy()
+    row_ptr = np.concatenate([[0], np.cumsum(deg_s)]).astype(np.int32)
+    nnz = int(row_ptr[-1])
+    csr = sp.csr_matrix((np.arange(nnz, dtype=np.int32), cols_l, row_ptr), shape=(ns, ns))
+    csc = csr.tocsc()
+    sub = dict(n=ns, nnz=nnz, row_ptr=row_ptr, col_ind=cols_l, col_ptr=csc.indptr.astype(np.int32),
+               row_ind=csc.indices.astype(np.int32), permute=csc.data.astype(np.int32))
+    return nodes, sub, rows_l.cpu().numpy()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_sampled_rows_against_the_oracle(big):
+    g = big["g"]
+    rp = g["row_ptr"].long()
+    deg = rp[1:] - rp[:-1]
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(7)
+    rows = torch.randint(0, g["n"], (3000,), device=DEV, generator=gen)
+    rows = torch.unique(torch.cat([rows, torch.topk(deg, 4).indices,            # the longest rows
+                                   torch.tensor([0, g["n"] - 1], device=DEV)]))
+    nodes, sub, rl = cut_rows(g, rows)
+    x, ar, ac, grad = (host(big[k][nodes]) for k in ("x", "ar", "ac", "grad"))
+    o64, m64, s64 = oracle.gat_forward_f64(ar, ac, sub["row_ptr"], sub["col_ind"], SLOPE, x, 0.0)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(SLOPE, 0.0, sub["row_ptr"], sub["col_ind"], None, x, ar, ac, grad)
+    m_out, _, m_gr, _ = gat_masses(sub, ar, ac, x, grad, SLOPE)
+    assert_close(host(big["out"][rows]), o64[rl], "out_feat (sampled rows)", mass=m_out[rl])
+    assert_close(host(big["esum"][rows]), s64[rl], "edge_sum (sampled rows)")
+    _, m32, _ = oracle.gat_forward(ar, ac, sub["row_ptr"], sub["col_ind"], SLOPE, x, 0.0)
+    assert np.array_equal(host(big["emax"][rows]), m32[rl]), "edge_max is the reference's float max"
+    # grad_attn_row[r] needs only row r's edges, grad[r] and the touched in_feat rows
+    assert_close(host(big["gr"][rows]), gr64[rl], "grad_attn_row (sampled rows)", mass=m_gr[rl])
+
+
+def test_sampled_columns_against_the_oracle(big):
+    g = big["g"]
+    cp = g["col_ptr"].long()
+    cdeg = cp[1:] - cp[:-1]
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(8)
+    cols = torch.randint(0, g["n"], (200,), device=DEV, generator=gen)
+    # plus one hub-like column whose sub-problem the oracle still finishes in seconds
+    mid = torch.nonzero((cdeg >= 1000) & (cdeg <= 2500)).flatten()
+    if mid.numel():
+        cols = torch.cat([cols, mid[:1]])
+    cols = torch.unique(cols)
+    # rows with an edge into a sampled column: grad_feat[c] and grad_attn_col[c] need each of
+    # those rows complete (softmax statistics and S)
+    d = cdeg[cols]
+    off = torch.cumsum(d, 0) - d
+    eidx = torch.repeat_interleave(cp[cols] - off, d) + torch.arange(int(d.sum()), device=DEV)
+    rows = torch.unique(g["row_ind"].long()[eidx])
+    nodes, sub, _ = cut_rows(g, rows)
+    cl = torch.searchsorted(nodes, cols).cpu().numpy()
+    x, ar, ac, grad = (host(big[k][nodes]) for k in ("x", "ar", "ac", "grad"))
+    gf64, gr64, gc64 = oracle.gat_backward_f64(SLOPE, 0.0, sub["row_ptr"], sub["col_ind"], None, x, ar, ac, grad)
+    _, m_gf, _, m_gc = gat_masses(sub, ar, ac, x, grad, SLOPE)
+    assert_close(host(big["gf"][cols]), gf64[cl], "grad_feat (sampled columns)", mass=m_gf[cl])
+    assert_close(host(big["gc"][cols]), gc64[cl], "grad_attn_col (sampled columns)", mass=m_gc[cl])
