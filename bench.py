@@ -259,8 +259,21 @@ def main():
         else:   # generic kernels in use: fall back to the call-level times
             dom = ("gat_backward call", ab["bwd_csc"], tb, "bwd") if tb >= tf else ("gat_forward call", ab["fwd"], tf, "fwd")
         achieved = dom[1] / (dom[2] * 1e-3) / 1e9
+        # device-copy bandwidth of this very GPU, same run: a 2 GiB
+        # device-to-device copy, read + written bytes over the event-timed duration
+        src = torch.empty(1 << 31, dtype=torch.uint8, device=device)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        ev[0].record()
+        for _ in range(5):
+            dst.copy_(src)
+        ev[1].record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+        del src, dst
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom[3]),
+                "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                 "kernel": dom[0], "algorithmic_bytes": dom[1], "kernel_ms": round(dom[2], 3),
                 "fwd_kernel_ms": round(kf, 3), "bwd_kernel_ms": round(kb, 3),
                 "fwd_call_ms": round(tf, 3), "bwd_call_ms": round(tb, 3),

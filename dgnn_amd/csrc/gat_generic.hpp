@@ -175,15 +175,17 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_bwd_col(
 // H == 4 fast path: a 16-lane group owns DGNN_ROWSUM_R consecutive rows and issues the first
 // two 256-byte steps of ALL of them before reducing (8 independent float4 loads in flight per
 // lane: the per-row work is tiny, so the kernel lives on memory-level parallelism); longer rows
-// continue in a loop.  Rows beyond DGNN_ROWSUM_LONG edges are finished by the whole block with a
-// fixed reduction tree.  Everything is a fixed-order sum: deterministic.
+// continue in a loop.  Rows beyond `long_thr` edges (rowsum_long_threshold(), a few hundred: on a
+// power-law graph the heavy rows sit next to each other, and a block lives as long as its
+// slowest 16-lane group) are queued and finished by one whole block each with a fixed reduction
+// tree.  Everything is a fixed-order sum: deterministic.
 #define DGNN_ROWSUM_LONG 4096
 #define DGNN_ROWSUM_R 4
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4(int m, const int *__restrict__ row_ptr,
                                                              const float4 *__restrict__ d4,
                                                              float4 *__restrict__ grad_attn_row,
                                                              int *__restrict__ long_count,
-                                                             int *__restrict__ long_list) {
+                                                             int *__restrict__ long_list, int long_thr) {
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
   const int rows_per_block = 16 * DGNN_ROWSUM_R;
   const int rg = blockIdx.x * rows_per_block + grp * DGNN_ROWSUM_R;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4(int m, const int *_
     hb[i] = __shfl(myptr, i + 1, 16);
     skip[i] = rg + i >= m;
     if (skip[i]) { lb[i] = 0; hb[i] = 0; }
-    if (hb[i] - lb[i] > DGNN_ROWSUM_LONG) {
+    if (hb[i] - lb[i] > long_thr) {
       // hub row: queued for k_gat_row_sum4_long (one whole block per hub row).  The queue order
       // varies from run to run, the value written for each row does not.
       if (q == 0) long_list[atomicAdd(long_count, 1)] = rg + i;

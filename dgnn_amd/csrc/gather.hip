@@ -142,6 +142,16 @@ struct BwdLayout {
   int max_long;
 };
 
+// Rows longer than this are summed by one block each (k_gat_row_sum4_long).  Tuning override:
+// DGNN_ROWSUM_LONG (read once per process: the workspace layout depends on it).
+int rowsum_long_threshold() {
+  static const int v = [] {
+    const int e = env_int("DGNN_ROWSUM_LONG", 256);
+    return (e >= 32 && e <= (1 << 20)) ? e : 256;
+  }();
+  return v;
+}
+
 bool bwd_fast_shape(int m, int n, int h, int f) {
   return !force_generic() && (h == 1 || h == 2 || h == 4 || h == 8) && (f % 4 == 0) &&
          (h * f <= 256) && is_pow2(f / 4) && m < (1 << 30) && n < (1 << 30);
@@ -155,7 +165,7 @@ BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
   o += align_up(sizeof(float) * (size_t)m * h, 256);
   w.off_dE = o;
   o += align_up(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1) * h, 256);
-  w.max_long = nnz / DGNN_ROWSUM_LONG + 1;       // rows with more than DGNN_ROWSUM_LONG edges
+  w.max_long = nnz / rowsum_long_threshold() + 1;   // rows with more edges than the threshold
   w.off_long = o;                                // [0] = counter, [1..] = queue
   o += align_up(sizeof(int) * ((size_t)w.max_long + 1), 256);
   if (w.fast) {
@@ -364,7 +374,7 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(k_gat_row_sum4, dim3((m + rows_per_block - 1) / rows_per_block),
                          dim3(DGNN_BLOCK), 0, st, m, row_ptr, (const float4 *)dE,
-                         (float4 *)grad_attn_row, long_count, long_count + 1);
+                         (float4 *)grad_attn_row, long_count, long_count + 1, rowsum_long_threshold());
       DGNN_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_gat_row_sum4_long, dim3(w.max_long), dim3(DGNN_BLOCK), 0, st, row_ptr,
                          (const float4 *)dE, (float4 *)grad_attn_row, (const int *)long_count,
