@@ -45,6 +45,7 @@ SIGNATURES = {
     "dgnn_csr2csc_workspace_bytes": (_sz, [_i, _i, _i]),
     "dgnn_csr2csc": (_i, [_i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_coo2csr": (_i, [_i, _i] + [_vp] * 2 + [_vp]),
+    "dgnn_knn_graph": (_i, [_i, _i, _i, _i] + [_vp] * 2 + [_vp]),
 }
 
 _lib = None

@@ -209,6 +209,17 @@ int dgnn_csr2csc(int m, int n, int nnz, const int *row_ptr, const int *col_ind, 
 /* Sorted COO row indices -> row_ptr [m+1].  Replaces coo2csr_cuda(), convert_kernel.cu:51-59. */
 int dgnn_coo2csr(int m, int nnz, const int *coo_row, int *row_ptr, void *stream);
 
+/* Exact k-nearest-neighbour graph per point cloud: x [batch, points, dim] -> src_ind
+ * [batch*points*k], src_ind[r*k + t] = global id (cloud offset included) of the t-th nearest
+ * point of r within r's cloud, r itself included, ascending distance, ties -> lower id: the
+ * layout edgeconv_forward consumes (fused_edgeconv_kernel.cu:21-27).  Replaces the DGL call in
+ * front of the fused EdgeConv, KNNGraph(k)(h) + g.edges(), script/train/train_edgeconv.py:17,
+ * 49-52 (third-party: dgl >= 0.7, README.md:29; not under the reference tree).  Distances are
+ * the float32 fma chain sum_f (x_i[f]-x_j[f])^2, f ascending, so the selection is reproducible
+ * bit for bit.  k <= min(points, 64). */
+int dgnn_knn_graph(int batch, int points, int dim, int k, const float *x, int *src_ind,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

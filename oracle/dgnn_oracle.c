@@ -680,3 +680,49 @@ void oracle_coo2csr(int m, int nnz, const int *coo_row, int *row_ptr) {
   for (int e = 0; e < nnz; ++e) row_ptr[coo_row[e] + 1]++;
   for (int r = 0; r < m; ++r) row_ptr[r + 1] += row_ptr[r];
 }
+
+/* ---------------------------------------------------------------------------
+ * k-nearest-neighbour graph in front of EdgeConv.  The reference takes it from DGL
+ * (KNNGraph(k)(h); src, dst = g.edges(): script/train/train_edgeconv.py:17,49-52; dgl >= 0.7,
+ * README.md:29 -- third-party, not under the reference tree).  DGL's published algorithm
+ * (bruteforce): pairwise squared distances inside each cloud, the k smallest per point
+ * (the point itself included), src = neighbour, dst = point repeated k times.  Restated with
+ * a pinned float32 distance chain (f ascending, fmaf) and a total order (distance, then id),
+ * which fixes what DGL leaves to topk's tie handling.  Index parity with DGL itself: unpinned.
+ * ------------------------------------------------------------------------- */
+void oracle_knn(int batch, int points, int dim, int k, const float *x, int *src_ind) {
+#pragma omp parallel
+  {
+    float *d = (float *)malloc(sizeof(float) * (size_t)(points > 0 ? points : 1));
+#pragma omp for schedule(static)
+    for (long long q = 0; q < (long long)batch * points; ++q) {
+      const int b = (int)(q / points);
+      const float *xc = x + (size_t)b * points * dim;
+      const float *xi = x + (size_t)q * dim;
+      for (int j = 0; j < points; ++j) {
+        float acc = 0.f;
+        for (int f = 0; f < dim; ++f) {
+          const float t = xi[f] - xc[(size_t)j * dim + f];
+          acc = fmaf(t, t, acc);
+        }
+        d[j] = acc;
+      }
+      /* k rounds of selection: smallest (distance, id) not yet taken */
+      float last_d = -1.f;
+      int last_j = -1;
+      for (int t = 0; t < k; ++t) {
+        int bj = -1;
+        float bd = 0.f;
+        for (int j = 0; j < points; ++j) {
+          const float dj = d[j];
+          if (dj < last_d || (dj == last_d && j <= last_j)) continue; /* already taken */
+          if (bj < 0 || dj < bd) { bj = j; bd = dj; }
+        }
+        src_ind[(size_t)q * k + t] = bj < 0 ? -1 : b * points + bj;
+        last_d = bd;
+        last_j = bj;
+      }
+    }
+    free(d);
+  }
+}

@@ -19,7 +19,7 @@ __all__ = [
     "spmm_csr", "spmm_csr_f64", "mhsddmm", "mhsddmm_f64", "mhtranspose",
     "gmmconv", "gmmconv_f64", "gaussian", "gaussian_bp", "gaussian_bp_f64",
     "edgeconv_forward", "edgeconv_backward", "edgeconv_backward_f64",
-    "csr2csc", "coo2csr",
+    "csr2csc", "coo2csr", "knn_graph",
 ]
 
 
@@ -293,3 +293,14 @@ def coo2csr(coo_row, m):
     row_ptr = np.empty(int(m) + 1, np.int32)
     _L().oracle_coo2csr(_I(int(m)), _I(coo_row.shape[0]), _p(coo_row), _p(row_ptr))
     return row_ptr
+
+
+def knn_graph(x, k):
+    """x [batch, points, dim] float32 -> src_ind [batch*points*k] int32 (DGL KNNGraph + g.edges()
+    as used at script/train/train_edgeconv.py:49-52; pinned distance chain and tie rule)."""
+    x = _f32(x)
+    assert x.ndim == 3
+    b, pts, dim = x.shape
+    out = np.empty(b * pts * int(k), np.int32)
+    _L().oracle_knn(_I(b), _I(pts), _I(dim), _I(int(k)), _p(x), _p(out))
+    return out

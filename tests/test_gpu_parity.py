@@ -293,3 +293,51 @@ def test_edgeconv_continuous_values_and_operator(nat):
     assert np.array_equal(host(out), ref_out)
     assert_close(host(hs.grad), oracle.edgeconv_backward_f64(go, ref_idx.astype(np.int32)), "grad_src", atol=1e-5)
     assert np.array_equal(host(hd.grad), go)
+
+
+# ----------------------------------------------------------------------------- k-NN graph
+@pytest.mark.parametrize("b,p,dim,k", [
+    (3, 50, 3, 5), (2, 300, 3, 20), (2, 257, 64, 20), (1, 1000, 128, 20), (2, 90, 200, 33),
+    (1, 64, 16, 64), (5, 20, 1, 1), (1, 31, 7, 31), (2, 2048, 3, 20), (1, 515, 300, 9)])
+def test_knn_graph_bit_exact(b, p, dim, k):
+    from dgnn_amd.native.knn import knn_graph
+    rng = np.random.default_rng(b * 1000 + p + dim)
+    x = rng.standard_normal((b, p, dim)).astype(np.float32)
+    got = host(knn_graph(dev(x), k))
+    want = oracle.knn_graph(x, k)
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+
+
+def test_knn_graph_ties_duplicates_and_errors():
+    import dgnn_amd
+    from dgnn_amd.native.knn import knn_graph
+    grid = np.stack(np.meshgrid(np.arange(12), np.arange(12), indexing="ij"), -1).reshape(1, 144, 2)
+    grid = np.repeat(grid, 2, 0).astype(np.float32)       # many exactly equal distances
+    assert np.array_equal(host(knn_graph(dev(grid), 9)), oracle.knn_graph(grid, 9))
+    dup = np.zeros((2, 40, 5), np.float32)                # all points identical
+    got = host(knn_graph(dev(dup), 6)).reshape(2, 40, 6)
+    assert np.array_equal(got[0], np.tile(np.arange(6), (40, 1)))
+    assert np.array_equal(got[1], np.tile(np.arange(6) + 40, (40, 1)))
+    one = dev(np.ones((10, 3), np.float32))               # [points, dim] = one cloud
+    assert knn_graph(one, 2).numel() == 20
+    with pytest.raises(dgnn_amd._lib.DgnnError):
+        knn_graph(dev(np.zeros((1, 4, 3), np.float32)), 5)   # k > points
+    with pytest.raises(dgnn_amd._lib.DgnnError):
+        knn_graph(torch.zeros((1, 4, 3)), 2)                 # CPU tensor: no fallback
+
+
+def test_knn_feeds_edgeconv_like_the_reference_model():
+    """DGCNN block of script/train/train_edgeconv.py:48-53 with our KNNGraph stand-in."""
+    from dgnn_amd.layers import EdgeConv, KNNGraph
+    torch.manual_seed(0)
+    x = torch.randn((4, 128, 3), device=DEV)
+    k = 10
+    src = KNNGraph(k)(x)
+    conv = EdgeConv(3, 16).to(DEV)
+    h = x.view(-1, 3).clone().requires_grad_()
+    out = conv(k, src, h)
+    out.sum().backward()
+    # reference formula in plain torch: max_j theta(x_j - x_i) + phi(x_i) (edgeconv_layer.py)
+    hs, hd = conv.theta(h), conv.phi(h) - conv.theta(h)
+    want = (hs[src.long()].view(-1, k, 16) + hd[:, None, :]).max(1).values
+    assert torch.allclose(out, want, rtol=1e-5, atol=1e-6)

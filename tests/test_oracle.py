@@ -236,3 +236,36 @@ def test_reference_arithmetic_needs_mass_term_on_hubs():
     strict_bad = sum(int((np.abs(a - b) > ATOL + RTOL * np.abs(b)).sum())
                      for a, b in ((gf32, gf64), (gr32, gr64), (gc32, gc64)))
     assert strict_bad > 0, "expected the plain band to be too tight for the reference's own float32 sums"
+
+
+# ----------------------------------------------------------------------------- k-NN graph
+def _knn_numpy(x, k):
+    """Independent statement: float64 distances, stable argsort (ties -> lower id)."""
+    b, p, _ = x.shape
+    x64 = x.astype(np.float64)
+    out = np.empty((b, p, k), np.int64)
+    for c in range(b):
+        d = ((x64[c][:, None, :] - x64[c][None, :, :]) ** 2).sum(-1)
+        out[c] = np.argsort(d, axis=1, kind="stable")[:, :k] + c * p
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("b,p,dim,k", [(3, 50, 3, 5), (2, 64, 16, 20), (1, 33, 70, 33), (4, 20, 1, 1)])
+def test_knn_oracle_matches_numpy(b, p, dim, k):
+    rng = np.random.default_rng(b * 100 + p)
+    x = rng.standard_normal((b, p, dim)).astype(np.float32)
+    got = oracle.knn_graph(x, k)
+    want = _knn_numpy(x, k)
+    # float32 vs float64 distances can only reorder near-equal neighbours: none at these sizes
+    assert np.array_equal(got, want)
+    assert np.array_equal(got.reshape(b * p, k)[:, 0], np.arange(b * p)), "a point is its own nearest"
+
+
+def test_knn_oracle_tie_rule_lower_id_first():
+    # integer grid: many exactly equal distances
+    g = np.stack(np.meshgrid(np.arange(4), np.arange(4), indexing="ij"), -1).reshape(1, 16, 2).astype(np.float32)
+    got = oracle.knn_graph(g, 5).reshape(16, 5)
+    want = _knn_numpy(g, 5).reshape(16, 5)
+    assert np.array_equal(got, want)
+    dup = np.zeros((1, 6, 3), np.float32)              # all points identical
+    assert np.array_equal(oracle.knn_graph(dup, 4).reshape(6, 4), np.tile(np.arange(4), (6, 1)))

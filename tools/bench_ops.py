@@ -50,6 +50,20 @@ def edgeconv(batch=32, pts=2048, k=20):
                           "fwd_GBps": round(bf / tf / 1e6, 1), "bwd_GBps": round(bb / tb / 1e6, 1)}), flush=True)
 
 
+def knn(batch=32, pts=2048, k=20):
+    """k-NN graph of a ModelNet40-shaped batch in the feature spaces DGCNN builds it in
+    (script/train/train_edgeconv.py:49: input dims 3, 64, 64, 128)."""
+    from dgnn_amd.native.knn import knn_graph
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    for f in (3, 64, 128):
+        x = torch.randn((batch, pts, f), device=dev, generator=gen)
+        t = timeit(lambda: knn_graph(x, k), iters=5, warm=2)
+        pairs = batch * pts * pts
+        print(json.dumps({"op": "knn_graph", "batch": batch, "points": pts, "dim": f, "k": k, "ms": round(t, 4),
+                          "Gpairs_per_s": round(pairs / t / 1e6, 2),
+                          "fp32_TFLOPs": round(pairs * 3 * f / t / 1e9, 2)}), flush=True)
+
+
 def gmm_pubmed():
     from dgnn_amd.operators import GmmConvFuse
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -104,4 +118,4 @@ if __name__ == "__main__":
     ap.add_argument("which", nargs="*", default=["edgeconv", "gmm", "reddit"])
     a = ap.parse_args()
     for w in a.which:
-        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit}[w]()
+        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn}[w]()
