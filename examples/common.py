@@ -1,0 +1,79 @@
+"""Shared pieces of the example models: synthetic datasets of the reference's benchmark shapes
+(no dataset can be downloaded here), device-side graph preparation, and the reference scripts'
+measurement protocol (10 warm-up epochs, n timed epochs bracketed by device synchronisation, one
+CSV line: script/train/train_gatconv.py:125-172)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from dgnn_amd.native import format_conversion  # noqa: E402
+
+# name: (nodes, directed edges before self loops, input features, classes)
+CITATION_SHAPES = {
+    "cora": (2708, 10556, 1433, 7),
+    "citeseer": (3327, 9104, 3703, 6),
+    "pubmed": (19717, 88648, 500, 3),
+    "reddit": (232965, 114615892, 602, 41),
+}
+
+
+def prepare_graph(src, dst, n):
+    """Edges src->dst (int64 device tensors, any order, duplicates allowed) -> the five index
+    arrays every fused operator takes, built on the device: CSR by destination with ascending
+    sources, its CSC, and permute (the convention of script/train/train_gatconv.py:78-94)."""
+    key = torch.unique(dst * n + src)                       # sorted: rows, then columns
+    rows = (key // n).to(torch.int32)
+    col_ind = (key % n).to(torch.int32)
+    row_ptr = format_conversion.coo2csr(rows, n)
+    col_ptr, row_ind, permute = format_conversion.csr2csc_int(row_ptr, col_ind)
+    return row_ptr, col_ind, col_ptr, row_ind, permute
+
+
+def synthetic_citation(name, device, seed=0):
+    """Random graph + features + labels of a citation dataset's shape, self loops removed then
+    added as the reference scripts do (train_gatconv.py:75-76)."""
+    n, e, n_feats, n_classes = CITATION_SHAPES[name]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    src = torch.randint(0, n, (e,), device=device, generator=gen)
+    dst = torch.randint(0, n, (e,), device=device, generator=gen)
+    keep = src != dst
+    loops = torch.arange(n, device=device)
+    src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+    graph = prepare_graph(src, dst, n)
+    features = torch.randn((n, n_feats), device=device, generator=gen)
+    labels = torch.randint(0, n_classes, (n,), device=device, generator=gen)
+    train_mask = torch.rand(n, device=device, generator=gen) < 0.3
+    return dict(n=n, graph=graph, features=features, labels=labels, n_feats=n_feats,
+                n_classes=n_classes, train_mask=train_mask, test_mask=~train_mask)
+
+
+def time_epochs(fn, n_epochs, warmup=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start = time.time()
+    for _ in range(n_epochs):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - start) / n_epochs
+
+
+def max_memory_mb(device):
+    return int(torch.cuda.max_memory_allocated(device) // (1 << 20))
+
+
+def accuracy(logits, labels):
+    return (logits.argmax(1) == labels).float().mean().item()
+
+
+def append_csv(path, line):
+    print(line)
+    if path:
+        with open(path, "a") as f:
+            print(line, file=f)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""GAT on the fused GATConv layer: the model, training loop, timing protocol and CSV line of
+the reference's script/train/train_gatconv.py, on a synthetic graph of the named dataset's shape.
+
+    python examples/train_gatconv.py --dataset cora --n-heads 4 --n-hidden 64 --output out.csv
+"""
+import argparse
+
+import torch
+from torch import nn
+
+from common import accuracy, append_csv, max_memory_mb, synthetic_citation, time_epochs
+from dgnn_amd.layers import GATConv
+
+
+class Net(nn.Module):
+    """num_layers hidden GAT layers (heads concatenated) and a mean-over-heads output layer
+    (train_gatconv.py:11-53)."""
+
+    def __init__(self, graph, num_layers, in_dim, num_hidden, num_classes, heads, feat_drop=0.,
+                 attn_drop=0., negative_slope=0.2, residual=False):
+        super().__init__()
+        self.graph = graph
+        dims = [in_dim] + [num_hidden * heads[i] for i in range(num_layers)]
+        self.gat_layers = nn.ModuleList(
+            GATConv(dims[i], num_hidden, heads[i], feat_drop, attn_drop, negative_slope,
+                    residual if i else False, bias=bool(i)) for i in range(num_layers))
+        self.gat_layers.append(GATConv(dims[-1], num_classes, heads[-1], feat_drop, attn_drop,
+                                       negative_slope))
+
+    def forward(self, h):
+        for layer in self.gat_layers[:-1]:
+            h = layer(*self.graph, h).flatten(1)
+        return self.gat_layers[-1](*self.graph, h).mean(1)
+
+
+def main():
+    ap = argparse.ArgumentParser(description="GAT on dgnn_amd")
+    ap.add_argument("--dataset", default="cora", choices=["cora", "citeseer", "pubmed", "reddit"])
+    ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--weight-decay", type=float, default=5e-4)
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--n-epochs", type=int, default=200)
+    ap.add_argument("--n-hidden", type=int, default=16)
+    ap.add_argument("--n-layers", type=int, default=1)
+    ap.add_argument("--n-heads", type=int, default=1)
+    ap.add_argument("--negative-slope", type=float, default=0.2)
+    ap.add_argument("--attn-drop", type=float, default=0.)
+    ap.add_argument("--output", default=None)
+    args = ap.parse_args()
+    print(args)
+
+    device = torch.device(f"cuda:{args.gpu}")
+    torch.cuda.set_device(device)
+    torch.manual_seed(0)
+    data = synthetic_citation(args.dataset, device)
+    heads = [args.n_heads] * args.n_layers + [1]
+    model = Net(data["graph"], args.n_layers, data["n_feats"], args.n_hidden, data["n_classes"], heads,
+                feat_drop=args.dropout, attn_drop=args.attn_drop,
+                negative_slope=args.negative_slope).to(device)
+    loss_fcn = nn.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    feats, labels, train_mask = data["features"], data["labels"], data["train_mask"]
+    losses = []
+
+    def train_epoch():
+        loss = loss_fcn(model(feats)[train_mask], labels[train_mask])
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.detach())
+
+    def infer_epoch():
+        with torch.no_grad():
+            return model(feats)
+
+    model.train()
+    train_time = time_epochs(train_epoch, args.n_epochs)
+    model.eval()
+    inference_time = time_epochs(infer_epoch, args.n_epochs, warmup=0)
+    acc = accuracy(infer_epoch()[data["test_mask"]], labels[data["test_mask"]])
+    print(f"loss {losses[0].item():.4f} -> {losses[-1].item():.4f}; test accuracy {acc:.4f} (random labels)")
+    append_csv(args.output, "train_GAT_dgnn_amd,{} heads={} hidden_dim={},{:f}s,{:f}s,{}MB,{}".format(
+        args.dataset, args.n_heads, args.n_hidden, train_time, inference_time, max_memory_mb(device), acc))
+
+
+if __name__ == "__main__":
+    main()

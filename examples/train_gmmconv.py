@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""MoNet on the fused GMMConv layer (script/train/train_gmmconv.py: model :11-59, pseudo
+coordinates 1/sqrt(in-degree) of both end points :120-122, CSV :190) on a synthetic graph."""
+import argparse
+
+import torch
+from torch import nn
+
+from common import accuracy, append_csv, max_memory_mb, synthetic_citation, time_epochs
+from dgnn_amd.layers import GMMConv
+
+
+class MoNet(nn.Module):
+    def __init__(self, graph, in_feats, n_hidden, out_feats, n_layers, dim, n_kernels, dropout):
+        super().__init__()
+        self.graph = graph
+        dims = [in_feats] + [n_hidden] * n_layers + [out_feats]
+        self.layers = nn.ModuleList(GMMConv(dims[i], dims[i + 1], dim, n_kernels)
+                                    for i in range(n_layers + 1))
+        self.pseudo_proj = nn.ModuleList(nn.Sequential(nn.Linear(2, dim), nn.Tanh())
+                                         for _ in range(n_layers + 1))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, h, pseudo):
+        for i, (layer, proj) in enumerate(zip(self.layers, self.pseudo_proj)):
+            if i:
+                h = self.dropout(h)
+            h = layer(*self.graph, h, proj(pseudo))
+        return h
+
+
+def main():
+    ap = argparse.ArgumentParser(description="MoNet on dgnn_amd")
+    ap.add_argument("--dataset", default="pubmed", choices=["cora", "citeseer", "pubmed"])
+    ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--lr", type=float, default=1e-2)
+    ap.add_argument("--weight-decay", type=float, default=5e-5)
+    ap.add_argument("--n-epochs", type=int, default=200)
+    ap.add_argument("--n-hidden", type=int, default=16)
+    ap.add_argument("--n-layers", type=int, default=1)
+    ap.add_argument("--pseudo-dim", type=int, default=2)
+    ap.add_argument("--n-kernels", type=int, default=3)
+    ap.add_argument("--output", default=None)
+    args = ap.parse_args()
+    print(args)
+
+    device = torch.device(f"cuda:{args.gpu}")
+    torch.cuda.set_device(device)
+    torch.manual_seed(0)
+    data = synthetic_citation(args.dataset, device)
+    row_ptr, col_ind = data["graph"][0].long(), data["graph"][1].long()
+    # pseudo coordinates per edge, in CSR nnz order: 1/sqrt(in-degree) of source and
+    # destination (train_gmmconv.py:120-122)
+    deg = (row_ptr[1:] - row_ptr[:-1]).float()
+    dst = torch.repeat_interleave(torch.arange(data["n"], device=device), row_ptr[1:] - row_ptr[:-1])
+    pseudo = torch.stack([deg[col_ind].rsqrt(), deg[dst].rsqrt()], 1).contiguous()
+
+    model = MoNet(data["graph"], data["n_feats"], args.n_hidden, data["n_classes"], args.n_layers,
+                  args.pseudo_dim, args.n_kernels, args.dropout).to(device)
+    loss_fcn = nn.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    feats, labels, train_mask = data["features"], data["labels"], data["train_mask"]
+    losses = []
+
+    def train_epoch():
+        loss = loss_fcn(model(feats, pseudo)[train_mask], labels[train_mask])
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.detach())
+
+    def infer_epoch():
+        with torch.no_grad():
+            return model(feats, pseudo)
+
+    model.train()
+    train_time = time_epochs(train_epoch, args.n_epochs)
+    model.eval()
+    inference_time = time_epochs(infer_epoch, args.n_epochs, warmup=0)
+    acc = accuracy(infer_epoch()[data["test_mask"]], labels[data["test_mask"]])
+    print(f"loss {losses[0].item():.4f} -> {losses[-1].item():.4f}; test accuracy {acc:.4f} (random labels)")
+    append_csv(args.output, "train_GMM_dgnn_amd,{} pseudo_dim={} n_kernels={} hidden_dim={},{:f}s,{:f}s,{}MB".format(
+        args.dataset, args.pseudo_dim, args.n_kernels, args.n_hidden, train_time, inference_time,
+        max_memory_mb(device)))
+
+
+if __name__ == "__main__":
+    main()
