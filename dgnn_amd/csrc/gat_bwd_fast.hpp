@@ -46,10 +46,10 @@ struct BwdParams {
   float *slots;        // [2T][slot_stride]
 };
 
-static inline int bwd_group_size(int H) {
+static inline int bwd_group_size(int H, int nnz) {
   const int dflt = H <= 4 ? 256 : 128;
-  const int v = env_int("DGNN_BWD_L", dflt);   // tuning override: 64, 128 or 256
-  if (!(v == 64 || v == 128 || v == 256)) return dflt;
+  const int v = env_int("DGNN_BWD_L", 0);      // tuning override: 64, 128 or 256
+  if (!(v == 64 || v == 128 || v == 256)) return shrink_group_for_small_graphs(dflt, nnz, 64);
   return (H > 4 && v > 128) ? 128 : v;
 }
 static inline size_t bwd_lds_bytes(int H, int L) {

@@ -57,7 +57,7 @@ struct FwdLayout {
 
 FwdLayout fwd_layout(int nnz, int h, int f) {
   FwdLayout w;
-  w.L = fast_group_size(h);
+  w.L = fast_group_size(h, nnz);
   w.T = (nnz + w.L - 1) / w.L;
   w.slot_stride = (int)align_up((size_t)h * f + 2 * (size_t)h, 4);
   size_t o = 0;
@@ -169,7 +169,7 @@ BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
   w.off_long = o;                                // [0] = counter, [1..] = queue
   o += align_up(sizeof(int) * ((size_t)w.max_long + 1), 256);
   if (w.fast) {
-    w.L = bwd_group_size(h);
+    w.L = bwd_group_size(h, nnz);
     w.T = (nnz + w.L - 1) / w.L;
     w.slot_stride = (int)align_up((size_t)h * f + (size_t)h, 4);
     w.off_stat = o;

@@ -57,11 +57,19 @@ static inline int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
   return (e != nullptr && e[0] != 0) ? atoi(e) : dflt;
 }
+// A wave walks its group with only a few loads in flight, so a group costs ~L memory latencies
+// whatever the graph: small graphs get smaller groups until there are enough waves to fill
+// the 256 CUs (a Cora-sized graph with L = 512 would run on 26 waves).
+static inline int shrink_group_for_small_graphs(int L, int nnz, int min_L) {
+  while (L > min_L && (long long)nnz / L < 8192) L >>= 1;
+  return L;
+}
 // Tuning override (multiples of 64): DGNN_FWD_L.
-static inline int fast_group_size(int H) {
+static inline int fast_group_size(int H, int nnz) {
   const int dflt = H <= 4 ? 512 : 256;
-  const int v = env_int("DGNN_FWD_L", dflt);
-  return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : dflt;
+  const int v = env_int("DGNN_FWD_L", 0);
+  if (v >= 64 && v <= 1024 && v % 64 == 0) return v;
+  return shrink_group_for_small_graphs(dflt, nnz, 64);
 }
 static inline size_t fast_lds_bytes(int H, int L) {
   // per wave: weights [L*H] + column ids [L] + flush queue [L]

@@ -89,6 +89,32 @@ def test_gat_forward_backward(nat, name, h, f, p):
         assert_close(host(gc), gc64, f"grad_attn_col (out_feat={with_out})", mass=m_gc)
 
 
+@pytest.mark.parametrize("name", ["deg_edges", "powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("fwd_l,bwd_l", [(512, 256), (256, 128), (128, 64), (64, 64)])
+def test_gat_every_group_size(nat, name, fwd_l, bwd_l, monkeypatch):
+    """The library shrinks its neighbour groups on small graphs; the production sizes of the
+    big graphs (512 forward / 256 backward) are forced here on the small ones."""
+    monkeypatch.setenv("DGNN_FWD_L", str(fwd_l))
+    monkeypatch.setenv("DGNN_BWD_L", str(bwd_l))
+    g = GRAPHS[name]
+    h, f, slope = 4, 64, 0.2
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=13)
+    G = gdev(g)
+    d_in, d_ar, d_ac, d_grad = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    out, emax, esum, emask = nat["gat"].gat_forward(d_ar, d_ac, G["row_ptr"], G["col_ind"], slope, d_in, 0.0)
+    gf, gr, gc = nat["gat"].gat_backward(slope, 0.0, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"],
+                                         G["permute"], emax, esum, emask, d_in, d_ar, d_ac, d_grad, out_feat=out)
+    o64, m64, s64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope, in_feat, 0.0, None)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(slope, 0.0, g["row_ptr"], g["col_ind"], None, in_feat,
+                                               attn_row, attn_col, grad)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, slope)
+    assert_close(host(out), o64, "out_feat", mass=m_out)
+    assert_close(host(esum), s64, "edge_sum")
+    assert_close(host(gf), gf64, "grad_feat", mass=m_gf)
+    assert_close(host(gr), gr64, "grad_attn_row", mass=m_gr)
+    assert_close(host(gc), gc64, "grad_attn_col", mass=m_gc)
+
+
 @pytest.mark.parametrize("name", ["tiny", "powerlaw256", "rmat4k"])
 def test_gat_inference_and_tiles(nat, name):
     g = GRAPHS[name]
