@@ -4,7 +4,8 @@ initialisation and forward signature."""
 import torch
 from torch import nn
 
-from ..operators.fused_gatconv import GATConvFuse, GATConvFuse_inference
+from ..native import gat_layer_ops
+from ..operators.fused_gatconv import GATConvFuseFromFeat, GATConvFuse_inference, GATEpilogue
 
 
 class GATConv(nn.Module):
@@ -50,21 +51,25 @@ class GATConv(nn.Module):
         h = self.feat_drop(h)
         # attn_l is the DESTINATION (row) term, attn_r the SOURCE term (gatconv_layer.py:74-75;
         # the opposite of DGL's naming, test/func_test/func_gat_dgl.py:62)
-        attn_row = (self.attn_l * h).sum(dim=-1)
-        attn_col = (self.attn_r * h).sum(dim=-1)
+        # Both score terms come out of one pass over h (csrc/layer.hip) instead of two
+        # multiply + sum chains; in training their gradient is folded into the fused operator's
+        # grad_feat in place.
         if not self.training:
-            rst = GATConvFuse_inference(attn_row.contiguous(), attn_col.contiguous(), row_ptr,
-                                        col_ind, self.negative_slope, h.contiguous())
+            h = h.contiguous()
+            scores = gat_layer_ops.attn_scores(h.detach(), self.attn_l.detach().contiguous(),
+                                               self.attn_r.detach().contiguous())
+            if scores is None:
+                scores = ((self.attn_l * h).sum(dim=-1).contiguous(),
+                          (self.attn_r * h).sum(dim=-1).contiguous())
+            rst = GATConvFuse_inference(scores[0], scores[1], row_ptr, col_ind, self.negative_slope, h)
         else:
-            rst = GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute,
-                              self.negative_slope, h, self.attn_drop)
+            rst = GATConvFuseFromFeat(h, self.attn_l, self.attn_r, row_ptr, col_ind, col_ptr, row_ind,
+                                      permute, self.negative_slope, self.attn_drop)
+        res = None
         if self.res_fc is not None:
             # the reference applies res_fc to h (gatconv_layer.py:83), which only type-checks
             # when in_feats == out_feats*num_heads; apply it to the layer input in the Linear case
             src = h if isinstance(self.res_fc, nn.Identity) else feat
-            rst = rst + self.res_fc(src).view(-1, self.num_heads, self.out_feats)
-        if self.bias is not None:
-            rst = rst + self.bias.view(-1, self.num_heads, self.out_feats)
-        if self.activation:
-            rst = self.activation(rst)
-        return rst
+            res = self.res_fc(src).view(-1, self.num_heads, self.out_feats)
+        # residual + bias + activation in one pass (gatconv_layer.py:82-90)
+        return GATEpilogue(rst, res, self.bias, self.activation if self.activation else None)

@@ -45,3 +45,106 @@ class FusedGATFunction(torch.autograd.Function):
             edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad_out, out_feat=out_feat)
         # same tuple layout as fused_gatconv.py:34
         return grad_attn_row, grad_attn_col, None, None, None, None, None, None, grad_feat, None
+
+
+# ------------------------------------------------------------------------------------------
+# Layer-level fusion (no counterpart in dgNN/operators): the score terms
+# computed from the projected features in one pass, the fused operator, and in the backward
+# the score terms' gradient accumulated into grad_feat in place.
+from ..native import gat_layer_ops as _lo  # noqa: E402
+
+
+def GATConvFuseFromFeat(feat, attn_l, attn_r, row_ptr, col_ind, col_ptr, row_ind, permute,
+                        negative_slope, attn_drop):
+    """out = GATConvFuse(<attn_l,feat>, <attn_r,feat>, graph..., feat, attn_drop) with
+    feat [n,h,f], attn_l / attn_r [1,h,f] (gatconv_layer.py:74-80 as one autograd node)."""
+    return FusedGATFromFeatFunction.apply(feat, attn_l, attn_r, row_ptr, col_ind, col_ptr, row_ind,
+                                          permute, negative_slope, attn_drop)
+
+
+class FusedGATFromFeatFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, attn_l, attn_r, row_ptr, col_ind, col_ptr, row_ind, permute,
+                negative_slope, attn_drop):
+        feat, attn_l, attn_r = feat.contiguous(), attn_l.contiguous(), attn_r.contiguous()
+        scores = _lo.attn_scores(feat, attn_l, attn_r)
+        ctx.fused_scores = scores is not None
+        if scores is None:                       # shape outside the kernel's range
+            scores = (attn_l * feat).sum(-1), (attn_r * feat).sum(-1)
+        attn_row, attn_col = scores
+        out_feat, edge_max, edge_sum, edge_mask = fused_gat.gat_forward(
+            attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, attn_drop)
+        ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
+                              edge_mask, feat, attn_row, attn_col, out_feat, attn_l, attn_r)
+        ctx.negative_slope = negative_slope
+        ctx.attn_drop = attn_drop
+        return out_feat
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, feat,
+         attn_row, attn_col, out_feat, attn_l, attn_r) = ctx.saved_tensors
+        grad_feat, g_row, g_col = fused_gat.gat_backward(
+            ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
+            edge_max, edge_sum, edge_mask, feat, attn_row, attn_col, grad_out.contiguous(),
+            out_feat=out_feat)
+        if ctx.fused_scores:
+            g_l, g_r = _lo.attn_scores_backward(feat, attn_l, attn_r, g_row, g_col, grad_feat)
+        else:
+            g_l = (g_row.unsqueeze(-1) * feat).sum(0, keepdim=True).view_as(attn_l)
+            g_r = (g_col.unsqueeze(-1) * feat).sum(0, keepdim=True).view_as(attn_r)
+            grad_feat = grad_feat + g_row.unsqueeze(-1) * attn_l + g_col.unsqueeze(-1) * attn_r
+        return grad_feat, g_l, g_r, None, None, None, None, None, None, None
+
+
+def _activation_code(activation):
+    """(code, param) of a callable the epilogue kernel implements, else None."""
+    import torch.nn.functional as F
+    from torch import nn
+    if activation is None:
+        return _lo.ACT_NONE, 0.0
+    if activation in (F.relu, torch.relu) or isinstance(activation, nn.ReLU):
+        return _lo.ACT_RELU, 0.0
+    if activation is F.elu:
+        return _lo.ACT_ELU, 1.0
+    if isinstance(activation, nn.ELU):
+        return _lo.ACT_ELU, float(activation.alpha)
+    if activation is F.leaky_relu:
+        return _lo.ACT_LEAKY_RELU, 0.01
+    if isinstance(activation, nn.LeakyReLU):
+        return _lo.ACT_LEAKY_RELU, float(activation.negative_slope)
+    return None
+
+
+def GATEpilogue(rst, residual, bias, activation):
+    """act(rst + residual + bias) in one pass (gatconv_layer.py:82-90); ``activation`` is a
+    callable; ones the kernel does not implement are applied by torch after the fused add."""
+    code = _activation_code(activation)
+    if code is None:
+        return activation(GATEpilogueFunction.apply(rst, residual, bias, _lo.ACT_NONE, 0.0))
+    if residual is None and bias is None and code[0] == _lo.ACT_NONE:
+        return rst
+    return GATEpilogueFunction.apply(rst, residual, bias, code[0], code[1])
+
+
+class GATEpilogueFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rst, residual, bias, act, act_param):
+        rst = rst.contiguous()
+        if residual is not None:
+            residual = residual.contiguous().view_as(rst)
+        out = _lo.epilogue(rst, residual, None if bias is None else bias.contiguous(), act, act_param)
+        ctx.save_for_backward(out)
+        ctx.act, ctx.act_param = act, act_param
+        ctx.has_res, ctx.has_bias = residual is not None, bias is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (out,) = ctx.saved_tensors
+        grad_pre, grad_bias = _lo.epilogue_backward(out, grad.contiguous(), ctx.act, ctx.act_param,
+                                                    ctx.has_bias and ctx.needs_input_grad[2])
+        if grad_bias is not None:
+            grad_bias = grad_bias.view(ctx.bias_shape)
+        return grad_pre, (grad_pre if ctx.has_res else None), grad_bias, None, None

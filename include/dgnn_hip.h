@@ -220,6 +220,43 @@ int dgnn_coo2csr(int m, int nnz, const int *coo_row, int *row_ptr, void *stream)
 int dgnn_knn_graph(int batch, int points, int dim, int k, const float *x, int *src_ind,
                    void *stream);
 
+/* ---- GAT layer steps on either side of the fused operator, one pass each -------------------
+ * attn_row[n,h] = <attn_l[h,:], feat[n,h,:]>, attn_col[n,h] = <attn_r[h,:], feat[n,h,:]>.
+ * Replaces the two multiply + sum chains of dgNN/layers/gatconv_layer.py:74-75 (attn_l is the
+ * destination/row term there).  Supported: f % 4 == 0 with f <= 256 and 16-byte aligned
+ * tensors, or f <= 64; otherwise DGNN_ERR_UNSUPPORTED (the caller keeps the torch expression). */
+int dgnn_gat_attn_scores(int n, int h, int f, const float *feat, const float *attn_l,
+                         const float *attn_r, float *attn_row, float *attn_col, void *stream);
+
+size_t dgnn_gat_attn_scores_backward_workspace_bytes(int n, int h, int f);
+
+/* Backward of the above, fused with the accumulation autograd would do afterwards:
+ * grad_feat[n,h,:] += g_row[n,h]*attn_l[h,:] + g_col[n,h]*attn_r[h,:]   (IN PLACE on grad_feat,
+ * normally the grad_feat dgnn_gat_backward just produced), grad_attn_l[h,:] = sum_n g_row[n,h]*
+ * feat[n,h,:], grad_attn_r likewise with g_col.  Fixed-order sums (deterministic). */
+int dgnn_gat_attn_scores_backward(int n, int h, int f, const float *feat, const float *attn_l,
+                                  const float *attn_r, const float *g_row, const float *g_col,
+                                  float *grad_feat, float *grad_attn_l, float *grad_attn_r,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* out = act(rst + residual + bias), residual [n,hf] and bias [hf] optional (NULL).  Replaces the
+ * elementwise tail of dgNN/layers/gatconv_layer.py:82-90.  activation: 0 none, 1 ReLU,
+ * 2 ELU(alpha = act_param), 3 LeakyReLU(slope = act_param). */
+#define DGNN_ACT_NONE 0
+#define DGNN_ACT_RELU 1
+#define DGNN_ACT_ELU 2
+#define DGNN_ACT_LEAKY_RELU 3
+int dgnn_gat_epilogue(int n, int hf, int activation, float act_param, const float *rst,
+                      const float *residual, const float *bias, float *out, void *stream);
+
+size_t dgnn_gat_epilogue_backward_workspace_bytes(int n, int hf);
+
+/* grad_pre = grad * act'(out) (the gradient of rst and of residual), grad_bias[hf] = column sums
+ * of grad_pre (optional, NULL to skip; fixed-order sums).  `out` is the forward OUTPUT. */
+int dgnn_gat_epilogue_backward(int n, int hf, int activation, float act_param, const float *out,
+                               const float *grad, float *grad_pre, float *grad_bias,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ __all__ = [
     "gmmconv", "gmmconv_f64", "gaussian", "gaussian_bp", "gaussian_bp_f64",
     "edgeconv_forward", "edgeconv_backward", "edgeconv_backward_f64",
     "csr2csc", "coo2csr", "knn_graph",
+    "gat_attn_scores_f64", "gat_attn_scores_backward_f64", "gat_epilogue_f64", "gat_epilogue_backward_f64",
 ]
 
 
@@ -304,3 +305,59 @@ def knn_graph(x, k):
     out = np.empty(b * pts * int(k), np.int32)
     _L().oracle_knn(_I(b), _I(pts), _I(dim), _I(int(k)), _p(x), _p(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GAT layer steps around the fused operator, float64 numpy (dgNN/layers/gatconv_layer.py).
+def gat_attn_scores_f64(feat, attn_l, attn_r):
+    """gatconv_layer.py:74-75: attn_row = (attn_l * h).sum(-1), attn_col = (attn_r * h).sum(-1)."""
+    x = np.asarray(feat, np.float64)
+    al = np.asarray(attn_l, np.float64).reshape(1, x.shape[1], x.shape[2])
+    ar = np.asarray(attn_r, np.float64).reshape(1, x.shape[1], x.shape[2])
+    return (al * x).sum(-1), (ar * x).sum(-1)
+
+
+def gat_attn_scores_backward_f64(feat, attn_l, attn_r, g_row, g_col):
+    """Gradients of the two sums above: (d feat, d attn_l [h,f], d attn_r [h,f])."""
+    x = np.asarray(feat, np.float64)
+    al = np.asarray(attn_l, np.float64).reshape(1, x.shape[1], x.shape[2])
+    ar = np.asarray(attn_r, np.float64).reshape(1, x.shape[1], x.shape[2])
+    gr = np.asarray(g_row, np.float64)[:, :, None]
+    gc = np.asarray(g_col, np.float64)[:, :, None]
+    return gr * al + gc * ar, (gr * x).sum(0), (gc * x).sum(0)
+
+
+def _act(v, activation, param):
+    if activation == 1:
+        return np.where(v > 0, v, 0.0)
+    if activation == 2:
+        return np.where(v > 0, v, param * np.expm1(np.minimum(v, 0.0)))
+    if activation == 3:
+        return np.where(v > 0, v, param * v)
+    return v
+
+
+def gat_epilogue_f64(rst, residual, bias, activation, param):
+    """gatconv_layer.py:82-90: rst (+ residual) (+ bias) then activation (0 none, 1 ReLU,
+    2 ELU(alpha), 3 LeakyReLU(slope))."""
+    v = np.asarray(rst, np.float64).copy()
+    if residual is not None:
+        v = v + np.asarray(residual, np.float64).reshape(v.shape)
+    if bias is not None:
+        v = v + np.asarray(bias, np.float64).reshape((1,) + v.shape[1:])
+    return _act(v, activation, param)
+
+
+def gat_epilogue_backward_f64(rst, residual, bias, activation, param, grad):
+    """-> (grad_pre, grad_bias): derivative at the pre-activation value."""
+    v = gat_epilogue_f64(rst, residual, bias, 0, 0.0)
+    if activation == 1:
+        d = (v > 0).astype(np.float64)
+    elif activation == 2:
+        d = np.where(v > 0, 1.0, param * np.exp(np.minimum(v, 0.0)))
+    elif activation == 3:
+        d = np.where(v > 0, 1.0, param)
+    else:
+        d = np.ones_like(v)
+    gp = np.asarray(grad, np.float64) * d
+    return gp, gp.reshape(gp.shape[0], -1).sum(0)
