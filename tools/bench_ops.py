@@ -64,6 +64,35 @@ def knn(batch=32, pts=2048, k=20):
                           "fp32_TFLOPs": round(pairs * 3 * f / t / 1e9, 2)}), flush=True)
 
 
+def layer(workload="products"):
+    """Whole GATConv layer (projection GEMM + score terms + fused operator + bias/ELU tail),
+    forward + backward: the layer as shipped against the same layer written with the
+    reference's chain of torch ops around the fused operator (gatconv_layer.py:68-92)."""
+    import torch.nn.functional as F
+    from dgnn_amd.layers import GATConv
+    from dgnn_amd.operators import GATConvFuse
+    g = bench.build_graph(workload, dev)
+    graph = [g[k] for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")]
+    n, in_feats, H, Fo = g["n"], 100, 4, 64
+    torch.manual_seed(0)
+    lay = GATConv(in_feats, Fo, H, activation=F.elu).to(dev)
+    feat = torch.randn((n, in_feats), device=dev, requires_grad=True)
+    go = torch.randn((n, H, Fo), device=dev)
+
+    def plain():
+        h = torch.matmul(feat, lay.W).view(-1, H, Fo)
+        rst = GATConvFuse((lay.attn_l * h).sum(-1), (lay.attn_r * h).sum(-1), *graph, lay.negative_slope, h, 0.0)
+        return F.elu(rst + lay.bias.view(-1, H, Fo))
+
+    def step(fn):
+        lay.zero_grad(); feat.grad = None
+        fn().backward(go)
+    t_fused = timeit(lambda: step(lambda: lay(*graph, feat)), iters=5, warm=2)
+    t_plain = timeit(lambda: step(plain), iters=5, warm=2)
+    print(json.dumps({"op": f"GATConv layer fwd+bwd ({workload}-shaped, in=100, 4x64, ELU)", "fused_ms": round(t_fused, 3),
+                      "torch_chain_ms": round(t_plain, 3)}), flush=True)
+
+
 def gmm_pubmed():
     from dgnn_amd.operators import GmmConvFuse
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -118,4 +147,4 @@ if __name__ == "__main__":
     ap.add_argument("which", nargs="*", default=["edgeconv", "gmm", "reddit"])
     a = ap.parse_args()
     for w in a.which:
-        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn}[w]()
+        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn, "layer": layer}[w]()
