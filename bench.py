@@ -119,14 +119,14 @@ def measured_traffic(workload, which):
 
 def cpu_baseline(name, seed=0):
     """The oracle (float32 restatement of the reference kernels, OpenMP over rows) timed on the
-    host cores on a bounded sample: an R-MAT graph of the same shape family scaled down so the
-    run takes seconds.  kind = "port" (the reference has no CPU path)."""
+    host cores on a bounded sample: an R-MAT graph of the same shape family at 1/8 scale (tens
+    of core-seconds).  kind = "port" (the reference has no CPU path)."""
     import oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import gat_inputs, rmat_graph
     n, target, scale = WORKLOADS[name]
-    div = 64 if name != "cora" else 1
-    ns, es, sc = max(n // div, 64), max(target // div, 256), max(scale - 6, 8) if div > 1 else scale
+    div = 8 if name != "cora" else 1          # ~2 s wall on 16 cores = ~30 core-seconds of CPU work
+    ns, es, sc = max(n // div, 64), max(target // div, 256), max(scale - 3, 8) if div > 1 else scale
     g = rmat_graph(sc, ns, max(es - ns, 1), seed)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], H, F, seed)
     cores = min(oracle.max_threads(), 16)
