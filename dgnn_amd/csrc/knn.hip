@@ -11,18 +11,15 @@
 // (x_i[f]-x_j[f])^2 in float32.  It is vector-ALU work, not a GEMM: the -2xy^T expansion would
 // not give the same bits and cancels badly for near neighbours.
 //
-// Mapping (gfx950, wave64): one thread owns one query point and keeps it in registers
-// (up to 128 dims at a time) together with its sorted candidate list; the block streams the
-// cloud's points through LDS in tiles of TJ candidates, every lane reads the same candidate
-// element (LDS broadcast, conflict-free), so one 16-byte LDS read feeds 8 vector ops per lane.
+// Mapping (gfx950, wave64): one lane owns one query point and keeps it in registers
+// (up to 128 dims at a time) together with its sorted candidate list; a wave streams its share
+// of the cloud's points through LDS in tiles, every lane reads the same candidate element
+// (LDS broadcast, conflict-free), so one 16-byte LDS read feeds 8 vector ops per lane.
 #include "../../include/dgnn_hip.h"
 #include "common.hpp"
 
 namespace dgnn {
 namespace {
-
-constexpr int KNN_TJ = 32;        // candidates per LDS tile
-constexpr int KNN_THREADS = 256;  // queries per block
 
 template <int KMAX>
 struct TopK {
@@ -53,18 +50,38 @@ struct TopK {
 
 // FC: query dims held in registers per chunk (multiple of 4).  SINGLE: dim <= FC, the query is
 // loaded once; otherwise the distance chain is carried across chunks through LDS.
+//
+// A block owns 64 query points; its four waves each scan a quarter of the cloud's candidates
+// for the SAME 64 queries (lane = query) with a private LDS tile, so waves never wait for one
+// another while scanning and there are 4x as many waves as queries/64 to hide LDS and VALU
+// latency.  The four sorted lists are merged by wave 0 through LDS in part order, which keeps
+// the tie rule (a later part only holds higher ids).
+constexpr int KNN_PARTS = DGNN_WAVES_PER_BLOCK;   // 4
+
+static inline int knn_tile(int fc) { return fc >= 128 ? 16 : 32; }    // candidates per LDS tile
+static inline size_t knn_lds_bytes(int fc, bool single, int k) {
+  const size_t tile = (size_t)KNN_PARTS * knn_tile(fc) * fc * sizeof(float);
+  const size_t carry = single ? 0 : (size_t)KNN_PARTS * knn_tile(fc) * 64 * sizeof(float);
+  const size_t lists = (size_t)(KNN_PARTS - 1) * k * 64 * 2 * sizeof(float);
+  return tile + carry > lists ? tile + carry : lists;
+}
+
 template <int KMAX, int FC, bool SINGLE>
-__global__ __launch_bounds__(KNN_THREADS) void k_knn(int points, int dim, int k,
-                                                     const float *__restrict__ x,
-                                                     int *__restrict__ src_ind) {
-  __shared__ __align__(16) float tile[KNN_TJ * FC];
-  extern __shared__ __align__(16) float carry[];   // [KNN_TJ][KNN_THREADS] when !SINGLE
+__global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, int tj,
+                                                    const float *__restrict__ x,
+                                                    int *__restrict__ src_ind) {
+  extern __shared__ __align__(16) float lds[];
+  const int part = wave_in_block(), lane = lane_id();
+  float *tile = lds + (size_t)part * tj * FC;                                   // [tj][FC]
+  float *carry = lds + (size_t)KNN_PARTS * tj * FC + (size_t)part * tj * 64;    // [tj][64], !SINGLE
   const int b = blockIdx.y;
-  const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
   const bool active = i < points;
   const float *xc = x + (size_t)b * points * dim;          // this cloud
   const float *xi_ptr = xc + (size_t)(active ? i : 0) * dim;
   const int nchunks = SINGLE ? 1 : (dim + FC - 1) / FC;
+  const int per = (points + KNN_PARTS - 1) / KNN_PARTS;
+  const int jbeg = uniform_i32(part * per), jend = uniform_i32(min(points, (part + 1) * per));
 
   float xi[FC];
   if (SINGLE) {
@@ -74,22 +91,24 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(int points, int dim, int k,
   TopK<KMAX> best;
   best.init();
 
-  for (int j0 = 0; j0 < points; j0 += KNN_TJ) {
-    const int jn = min(KNN_TJ, points - j0);
+  for (int j0 = jbeg; j0 < jend; j0 += tj) {
+    const int jn = min(tj, jend - j0);
     for (int c = 0; c < nchunks; ++c) {
       const int f0 = c * FC;
       if (!SINGLE) {
 #pragma unroll
         for (int f = 0; f < FC; ++f) xi[f] = (f0 + f < dim) ? xi_ptr[f0 + f] : 0.f;
       }
-      __syncthreads();                                     // previous tile fully consumed
-      for (int e = threadIdx.x; e < KNN_TJ * FC; e += KNN_THREADS) {
+      wave_lds_sync();                                     // previous tile fully consumed
+      for (int e = lane; e < tj * FC; e += 64) {
         const int j = e / FC, f = e - j * FC;
         tile[e] = (j < jn && f0 + f < dim) ? xc[(size_t)(j0 + j) * dim + f0 + f] : 0.f;
       }
-      __syncthreads();
+      wave_lds_sync();
+      // (two candidates at a time with packed-fp32 v_pk_fma_f32 was measured: no gain at 64 dims,
+      // 2.6x slower at 128 dims from the doubled query registers)
       for (int j = 0; j < jn; ++j) {
-        float acc = (SINGLE || c == 0) ? 0.f : carry[j * KNN_THREADS + threadIdx.x];
+        float acc = (SINGLE || c == 0) ? 0.f : carry[j * 64 + lane];
         const float4 *cj = (const float4 *)(tile + j * FC);
 #pragma unroll
         for (int f4 = 0; f4 < FC / 4; ++f4) {
@@ -104,29 +123,61 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(int points, int dim, int k,
         if (SINGLE || c == nchunks - 1) {
           best.push(acc, j0 + j);
         } else {
-          carry[j * KNN_THREADS + threadIdx.x] = acc;
+          carry[j * 64 + lane] = acc;
         }
       }
     }
   }
-  if (active) {
-    int *o = src_ind + ((size_t)b * points + i) * k;
-    const int base = b * points;
+  // merge: parts 1..3 publish their lists, wave 0 pushes them in part order
+  __syncthreads();                                         // every tile is dead from here on
+  float *ld = lds;                                         // [part-1][t][64] distances
+  int *li = (int *)(lds + (size_t)(KNN_PARTS - 1) * k * 64);   // same layout, ids
+  if (part > 0) {
 #pragma unroll
     for (int t = 0; t < KMAX; ++t)
-      if (t < k) o[t] = base + best.id[t];
+      if (t < k) {
+        ld[((size_t)(part - 1) * k + t) * 64 + lane] = best.d[t];
+        li[((size_t)(part - 1) * k + t) * 64 + lane] = best.id[t];
+      }
   }
+  __syncthreads();
+  if (part == 0) {
+    for (int p = 0; p < KNN_PARTS - 1; ++p)
+      for (int t = 0; t < k; ++t) {
+        const float dn = ld[((size_t)p * k + t) * 64 + lane];
+        const int jn2 = li[((size_t)p * k + t) * 64 + lane];
+        if (jn2 >= 0) best.push(dn, jn2);
+      }
+    if (active) {
+      int *o = src_ind + ((size_t)b * points + i) * k;
+      const int base = b * points;
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t)
+        if (t < k) o[t] = base + best.id[t];
+    }
+  }
+}
+
+// More than 64 KiB of dynamic LDS has to be allowed per kernel (k above ~40 in the merge).
+static int knn_allow_lds(const void *fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return DGNN_OK;
+  if (bytes > 160 * 1024) return DGNN_ERR_UNSUPPORTED;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? DGNN_OK : (int)e;
 }
 
 template <int KMAX>
 int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_ind, hipStream_t st) {
-  const dim3 grid((unsigned)((points + KNN_THREADS - 1) / KNN_THREADS), (unsigned)batch);
-  const dim3 block(KNN_THREADS);
-#define DGNN_KNN_CASE(FCV)                                                                       \
-  if (dim <= FCV) {                                                                              \
-    hipLaunchKernelGGL((k_knn<KMAX, FCV, true>), grid, block, 0, st, points, dim, k, x, src_ind); \
-    DGNN_LAUNCH_CHECK();                                                                         \
-    return DGNN_OK;                                                                              \
+  const dim3 grid((unsigned)((points + 63) / 64), (unsigned)batch);
+  const dim3 block(DGNN_BLOCK);
+#define DGNN_KNN_CASE(FCV)                                                                          \
+  if (dim <= FCV) {                                                                                 \
+    if (int rc = knn_allow_lds((const void *)k_knn<KMAX, FCV, true>, knn_lds_bytes(FCV, true, k)))  \
+      return rc;                                                                                    \
+    hipLaunchKernelGGL((k_knn<KMAX, FCV, true>), grid, block, knn_lds_bytes(FCV, true, k), st, points, \
+                       dim, k, knn_tile(FCV), x, src_ind);                                          \
+    DGNN_LAUNCH_CHECK();                                                                            \
+    return DGNN_OK;                                                                                 \
   }
   DGNN_KNN_CASE(4)
   DGNN_KNN_CASE(16)
@@ -134,8 +185,9 @@ int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_i
   DGNN_KNN_CASE(64)
   DGNN_KNN_CASE(128)
 #undef DGNN_KNN_CASE
-  hipLaunchKernelGGL((k_knn<KMAX, 128, false>), grid, block,
-                     sizeof(float) * KNN_TJ * KNN_THREADS, st, points, dim, k, x, src_ind);
+  if (int rc = knn_allow_lds((const void *)k_knn<KMAX, 128, false>, knn_lds_bytes(128, false, k))) return rc;
+  hipLaunchKernelGGL((k_knn<KMAX, 128, false>), grid, block, knn_lds_bytes(128, false, k), st, points, dim,
+                     k, knn_tile(128), x, src_ind);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }
