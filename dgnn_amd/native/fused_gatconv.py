@@ -77,6 +77,18 @@ def gat_forward_tb(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat
     return [out, edge_max, edge_sum]
 
 
+def make_tile_scheduler(row_ptr, tile=32):
+    """The (row, tile_in_row) list ``gat_forward_tb`` takes -- one pair per ``tile`` nonzeros of a
+    row -- built on row_ptr's device with index arithmetic instead of the reference's host loop
+    over all rows (script/test/test_gat_tb.py:16-26).  -> int32 [n_tiles, 2]."""
+    rp = row_ptr.to(torch.int64)
+    tiles = (rp[1:] - rp[:-1] + (tile - 1)) // tile
+    rid = torch.repeat_interleave(torch.arange(tiles.numel(), device=rp.device), tiles)
+    first = torch.cumsum(tiles, 0) - tiles
+    tin = torch.arange(rid.numel(), device=rp.device) - first[rid]
+    return torch.stack((rid, tin), 1).to(torch.int32).contiguous()
+
+
 def gat_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     """-> out_feat   (fused_gatconv.cpp:38-60)."""
     _check_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat)

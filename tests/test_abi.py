@@ -104,3 +104,19 @@ def test_dropin_modules_expose_reference_function_names():
     assert required(mhtranspose.mhtranspose) == ["permute", "attention"]
     assert required(format_conversion.csr2csc) == ["rowptr", "colind", "csr_data"]
     assert required(format_conversion.coo2csr) == ["cooRowInd", "m"]
+
+
+def test_tile_scheduler_builder_matches_the_reference_host_loop():
+    """make_tile_scheduler == the list script/test/test_gat_tb.py:16-26 builds row by row."""
+    import numpy as np
+    import torch
+    from dgnn_amd.native.fused_gatconv import make_tile_scheduler
+    rng = np.random.default_rng(0)
+    deg = rng.integers(0, 150, 300)
+    deg[[3, 77]] = 0
+    deg[5] = 32
+    deg[6] = 33
+    row_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    want = [(r, t) for r in range(300) for t in range((int(deg[r]) + 31) // 32)]
+    got = make_tile_scheduler(torch.from_numpy(row_ptr))
+    assert got.dtype == torch.int32 and got.tolist() == [list(p) for p in want]
