@@ -156,7 +156,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # a process group also for ONE rank when DGNN_DIST_FORCE_COLLECTIVES=1 (rehearsal of the whole
+    # multi-GPU path, RCCL calls included, on a one-GPU box; launch through torch.distributed.run)
+    use_pg = world > 1 or (os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
+    if use_pg:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -166,7 +169,7 @@ def main():
     import dgnn_amd  # noqa: F401
     from dgnn_amd.operators import GATConvFuse
 
-    if world > 1:
+    if use_pg:
         # one graph for everybody: rank 0 builds it, the index arrays are broadcast over RCCL
         import torch.distributed as dist
         g = build_graph(args.workload, device, seed=0) if rank == 0 else None
@@ -193,7 +196,7 @@ def main():
     attn_col = (torch.rand((n, H), device=device, generator=gen) - 0.4)
     grad_out = (torch.rand((n, H, F), device=device, generator=gen) - 0.5)
 
-    if world > 1 or args.force_dist:
+    if use_pg or args.force_dist:
         from dgnn_amd.dist import PartitionedGAT
         runner = PartitionedGAT(g, world, rank, device)
         step_fn = lambda: runner.step(in_feat, attn_row, attn_col, grad_out, SLOPE)
@@ -209,7 +212,7 @@ def main():
             out.backward(grad_out)
 
     def sync():
-        if world > 1:
+        if use_pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -221,7 +224,7 @@ def main():
         step_fn()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -232,7 +235,7 @@ def main():
     # launches on (dgnn_debug_last_kernel_ms); the whole forward / backward calls are also timed
     # with events on the same (torch current) stream.
     roof = None
-    if world == 1 and not args.force_dist:
+    if not use_pg and not args.force_dist:
         from dgnn_amd import _lib
         from dgnn_amd.native import fused_gatconv
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -297,7 +300,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 

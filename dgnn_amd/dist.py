@@ -102,6 +102,9 @@ class PartitionedGAT:
         self.world, self.rank, self.device, self.group = world, rank, device, group
         self.ops = ops if ops is not None else _NativeOps()
         self.mode = mode or os.environ.get("DGNN_DIST_MODE", "halo")
+        # one rank needs no collectives; DGNN_DIST_FORCE_COLLECTIVES=1 issues them anyway (a
+        # single-GPU rehearsal of the RCCL calls: tests/test_dist.py)
+        self._solo = world == 1 and os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") != "1"
         if self.mode not in ("halo", "allgather"):
             raise ValueError(f"unknown exchange mode {self.mode!r}")
         row_ptr, col_ind = graph["row_ptr"], graph["col_ind"]
@@ -140,10 +143,10 @@ class PartitionedGAT:
 
     # ------------------------------------------------------------------ collectives
     def _nccl(self):
-        return self.world > 1 and dist.get_backend(self.group) == "nccl"
+        return (not self._solo) and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
     def _a2a_counts(self, counts):
-        if self.world == 1:
+        if self._solo:
             return list(counts)
         dev = self.device if self._nccl() else torch.device("cpu")
         inp = torch.tensor(counts, dtype=torch.int64, device=dev)
@@ -153,7 +156,7 @@ class PartitionedGAT:
 
     def _a2a(self, out, inp, out_splits, in_splits):
         """out (rows grouped by source rank) <- inp (rows grouped by destination rank)."""
-        if self.world == 1:
+        if self._solo:
             out.copy_(inp)
             return out
         if self._nccl() or not inp.is_cuda:
@@ -188,7 +191,7 @@ class PartitionedGAT:
     def _all_gather_rows(self, local):
         """full[bounds[q]:bounds[q+1]] <- rank q's ``local`` rows, for every q."""
         full = torch.empty((self.n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        if self.world == 1:
+        if self._solo:
             full.copy_(local)
             return full
         views = [full[self.bounds[q]:self.bounds[q + 1]] for q in range(self.world)]
@@ -232,7 +235,7 @@ class PartitionedGAT:
         if self.mode == "halo":
             gr = self._return_rows(self.b_halo, gr_partial)
         else:
-            if self.world > 1:
+            if not self._solo:
                 dist.all_reduce(gr_partial, group=self.group)
             gr = gr_partial[self.lo:self.hi].contiguous()
         return gf, gr, gc

@@ -4,6 +4,9 @@ mode "cpu": gloo backend, CPU tensors, compute through a CPU stand-in built on t
             (test infrastructure: exercises the partition, block extraction, inverse
             permutation and collectives without a GPU).
 mode "gpu": gloo backend, every rank on cuda:0, compute through the real HIP kernels.
+mode "nccl1": ONE rank on cuda:0 with the nccl (= RCCL) backend and DGNN_DIST_FORCE_COLLECTIVES=1:
+            every collective of the step is really issued through RCCL (RCCL wants one GPU per
+            rank, so one rank is what a one-GPU box can rehearse).
 Each rank writes its local results to <out_dir>/rank<r>.npz; the parent assembles and checks.
 """
 import os
@@ -77,14 +80,18 @@ class OracleOps:
 def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "nccl1":      # one rank, RCCL backend, collectives forced: rehearses the calls on one GPU
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from util import gat_inputs, rmat_graph
     from dgnn_amd.dist import PartitionedGAT
     g = rmat_graph(*graph_spec)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
-    device = torch.device("cuda:0" if mode == "gpu" else "cpu")
+    device = torch.device("cpu" if mode == "cpu" else "cuda:0")
     G = {k: torch.from_numpy(g[k]).to(device) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
-    ops = None if mode == "gpu" else OracleOps()
+    ops = OracleOps() if mode == "cpu" else None
     runner = PartitionedGAT(G, world, rank, device, ops=ops)
     lo, hi = runner.lo, runner.hi
     t = lambda a: torch.from_numpy(a).to(device)

@@ -82,6 +82,15 @@ def test_partitioned_gat_gpu_two_ranks(exchange):
     check(run_world(2, "gpu", spec, h, f, exchange), spec, h, f)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_partitioned_gat_one_rank_through_rccl(exchange, monkeypatch):
+    """Every collective of the step issued through RCCL itself (one rank, collectives forced)."""
+    monkeypatch.setenv("DGNN_DIST_FORCE_COLLECTIVES", "1")
+    spec, h, f = (12, 4000, 60000, 7), 4, 64
+    check(run_world(1, "nccl1", spec, h, f, exchange), spec, h, f)
+
+
 def test_partition_bounds_balance_edges_not_nodes():
     import torch
     from dgnn_amd.dist import partition_bounds
