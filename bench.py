@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="products", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attn-drop", type=float, default=0.0,
+                    help="secondary run (test/gat_result.sh:10 uses 0.5); the headline is 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned path even with one rank (sanity check of dgnn_amd.dist)")
     args = ap.parse_args()
@@ -208,7 +210,7 @@ def main():
         def step_fn():
             x.grad = ar.grad = ac.grad = None
             out = GATConvFuse(ar, ac, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
-                              g["permute"], SLOPE, x, 0.0)
+                              g["permute"], SLOPE, x, args.attn_drop)
             out.backward(grad_out)
 
     def sync():
@@ -244,9 +246,10 @@ def main():
         xd, ard, acd = in_feat.detach(), attn_row.detach(), attn_col.detach()
         for _ in range(reps):
             ev[0].record()
-            out, emax, esum, emask = fused_gatconv.gat_forward(ard, acd, g["row_ptr"], g["col_ind"], SLOPE, xd, 0.0)
+            out, emax, esum, emask = fused_gatconv.gat_forward(ard, acd, g["row_ptr"], g["col_ind"], SLOPE, xd,
+                                                               args.attn_drop)
             ev[1].record()
-            fused_gatconv.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+            fused_gatconv.gat_backward(SLOPE, args.attn_drop, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
                                        g["permute"], emax, esum, emask, xd, ard, acd, grad_out, out_feat=out)
             ev[2].record()
             torch.cuda.synchronize()
@@ -291,7 +294,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
-                                   f"attn_drop=0, fused GATConvFuse fwd+bwd",
+                                   f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd",
                        "parallelism": "single GPU" if world == 1 else
                        f"row-partition x{world}, RCCL {os.environ.get('DGNN_DIST_MODE', 'halo')} exchange of boundary rows"},
         }

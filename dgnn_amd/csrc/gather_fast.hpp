@@ -275,13 +275,21 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     const float *wbase = sc + head;
     vec_t acc = V::zero();
     vec_t ring[DGNN_FAST_U];
+    float wring[DGNN_FAST_U];
+    // With a dropout mask a dropped (edge, head) has weight exactly 0: its lanes skip the load,
+    // so the dropped share of the feature traffic never leaves HBM (the reference loads the row
+    // and multiplies by 0, fused_gatconv_kernel.cu:95-117; identical for finite features).
+    const bool skip0 = (MODE == MODE_GAT) && (P.edge_mask != nullptr);
     int q = 0;
 #pragma unroll
     for (int k = 0; k < DGNN_FAST_U; ++k) {
       ring[k] = V::zero();
+      wring[k] = 0.f;
       if (k < cnt) {
         const unsigned c = uniform_i32((int)(cidx[k] & ~DGNN_ROWEND));
-        if (active) ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
+        wring[k] = wbase[(size_t)k * H];
+        if (active && !(skip0 && wring[k] == 0.f))
+          ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
       }
     }
     for (int j = 0; j < cnt; j += DGNN_FAST_U) {
@@ -290,12 +298,16 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         const int p = j + k;
         if (p < cnt) {
           const vec_t x = ring[k];
+          const float w = wring[k];
           const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
           if (p + DGNN_FAST_U < cnt) {
             const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
-            if (active) ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
+            wring[k] = wbase[(size_t)(p + DGNN_FAST_U) * H];
+            if (active && !(skip0 && wring[k] == 0.f))
+              ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
+            else
+              ring[k] = V::zero();
           }
-          const float w = wbase[(size_t)p * H];
           V::fma(acc, w, x);
           if (ci & DGNN_ROWEND) {
             const int d = uniform_i32(dq[q]);
