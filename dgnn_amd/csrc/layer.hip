@@ -47,7 +47,16 @@ struct Vec<1> {
 struct ScoreShape {
   int vec, G, spw, nw;
 };
-static bool score_shape(int h, int f, const void *a, const void *b, const void *c, ScoreShape *s) {
+static int score_waves(long long segs, int spw, int h) {
+  // at least ~4 passes per wave; a multiple of h so that a lane keeps its head; never more than
+  // the partial buffer holds (LAYER_WAVES + h waves)
+  long long want = (segs + (long long)spw * 4 - 1) / ((long long)spw * 4);
+  if (want > LAYER_WAVES) want = LAYER_WAVES;
+  if (want < 1) want = 1;
+  return (int)((want + h - 1) / h) * h;
+}
+static bool score_shape(long long segs, int h, int f, const void *a, const void *b, const void *c,
+                        ScoreShape *s) {
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   s->vec = (f % 4 == 0 && al16(a) && al16(b) && al16(c)) ? 4 : 1;
   const int slots = f / s->vec;
@@ -55,8 +64,7 @@ static bool score_shape(int h, int f, const void *a, const void *b, const void *
   s->G = 1;
   while (s->G < slots) s->G <<= 1;
   s->spw = 64 / s->G;
-  s->nw = (LAYER_WAVES / h) * h;
-  if (s->nw == 0) s->nw = h;
+  s->nw = score_waves(segs, s->spw, h);
   return true;
 }
 
@@ -136,22 +144,26 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_attn_scores_bwd(long long segs, 
   V::store(p + VEC, dr);
 }
 
-// d attn_l[h,f], d attn_r[h,f]: sum of the lane partials that belong to (h, f), in wave order.
-__global__ void k_attn_scores_bwd_reduce(int H, int F, int G, int nw, int vec,
-                                         const float *__restrict__ partial,
-                                         float *__restrict__ grad_attn_l,
-                                         float *__restrict__ grad_attn_r) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= 2 * H * F) return;
+// d attn_l[h,f], d attn_r[h,f]: sum of the lane partials that belong to (h, f).  One wave per
+// output element: lanes stride over the (wave, sub-segment) slots in a fixed pattern, then a
+// fixed butterfly -- the same bits every run.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_attn_scores_bwd_reduce(int H, int F, int G, int nw, int vec,
+                                                                       const float *__restrict__ partial,
+                                                                       float *__restrict__ grad_attn_l,
+                                                                       float *__restrict__ grad_attn_r) {
+  const int o = blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block();
+  if (o >= 2 * H * F) return;                        // wave-uniform exit
   const int which = o / (H * F), hf = o % (H * F), h = hf / F, f = hf % F;
   const int q = f / vec, comp = f % vec, spw = 64 / G;
+  const int slots = nw * spw;
   float acc = 0.f;
-  for (int w = 0; w < nw; ++w)
-    for (int sub = 0; sub < spw; ++sub) {
-      if ((int)(((long long)w * spw + sub) % H) != h) continue;
-      acc += partial[(((size_t)w * 64 + sub * G + q) * 2 + which) * vec + comp];
-    }
-  (which == 0 ? grad_attn_l : grad_attn_r)[hf] = acc;
+  for (int idx = lane_id(); idx < slots; idx += DGNN_WAVE) {
+    if (idx % H != h) continue;                      // slot idx = w*spw + sub serves head idx % H
+    const int w = idx / spw, sub = idx - w * spw;
+    acc += partial[(((size_t)w * 64 + sub * G + q) * 2 + which) * vec + comp];
+  }
+  acc = wave_sum(acc);
+  if (lane_id() == 0) (which == 0 ? grad_attn_l : grad_attn_r)[hf] = acc;
 }
 
 // ------------------------------------------------------------------------------- epilogue
@@ -219,19 +231,28 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue_bwd(long long total, lo
   }
   if (partial) partial[tid] = acc;
 }
-__global__ void k_epilogue_bwd_reduce(int hf, long long tt, const float *__restrict__ partial,
-                                      float *__restrict__ grad_bias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= hf) return;
+__global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue_bwd_reduce(int hf, long long tt,
+                                                                    const float *__restrict__ partial,
+                                                                    float *__restrict__ grad_bias) {
+  const int c = blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block();
+  if (c >= hf) return;                               // wave-uniform exit
   float acc = 0.f;
-  for (long long t = c; t < tt; t += hf) acc += partial[t];
-  grad_bias[c] = acc;
+  for (long long t = c + (long long)lane_id() * hf; t < tt; t += (long long)DGNN_WAVE * hf) acc += partial[t];
+  acc = wave_sum(acc);
+  if (lane_id() == 0) grad_bias[c] = acc;
 }
 
-static long long epi_threads(int hf) {
-  long long tt = (long long)EPI_BLOCKS * DGNN_BLOCK;
-  if (hf > tt) return hf;
-  return tt / hf * hf;
+// threads of k_epilogue_bwd: a multiple of hf (a thread keeps its column), ~8 rows per thread,
+// at most EPI_BLOCKS blocks worth
+static long long epi_threads_max(int hf) {
+  const long long cap = (long long)EPI_BLOCKS * DGNN_BLOCK;
+  return hf > cap ? hf : cap / hf * hf;
+}
+static long long epi_threads(int n, int hf) {
+  long long rows = ((long long)n + 7) / 8;
+  if (rows < 1) rows = 1;
+  const long long tt = rows * hf, cap = epi_threads_max(hf);
+  return tt < cap ? tt : cap;
 }
 
 }  // namespace
@@ -247,9 +268,9 @@ int dgnn_gat_attn_scores(int n, int h, int f, const float *feat, const float *at
   if (n == 0) return DGNN_OK;
   if (!feat || !attn_l || !attn_r || !attn_row || !attn_col) return DGNN_ERR_BAD_ARG;
   ScoreShape s;
-  if (!score_shape(h, f, feat, attn_l, attn_r, &s)) return DGNN_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
   const long long segs = (long long)n * h;
+  if (!score_shape(segs, h, f, feat, attn_l, attn_r, &s)) return DGNN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)blocks_for_waves(s.nw)), block(DGNN_BLOCK);
   if (s.vec == 4)
     hipLaunchKernelGGL(k_attn_scores<4>, grid, block, 0, st, segs, h, f, s.G, s.nw, feat, attn_l, attn_r,
@@ -263,8 +284,7 @@ int dgnn_gat_attn_scores(int n, int h, int f, const float *feat, const float *at
 
 size_t dgnn_gat_attn_scores_backward_workspace_bytes(int n, int h, int f) {
   if (n < 0 || h <= 0 || f <= 0) return 0;
-  const int nw = (LAYER_WAVES / h) * h > 0 ? (LAYER_WAVES / h) * h : h;
-  return sizeof(float) * (size_t)nw * 64 * 2 * 4;
+  return sizeof(float) * ((size_t)LAYER_WAVES + h) * 64 * 2 * 4;    // upper bound of score_waves()
 }
 
 int dgnn_gat_attn_scores_backward(int n, int h, int f, const float *feat, const float *attn_l,
@@ -275,20 +295,15 @@ int dgnn_gat_attn_scores_backward(int n, int h, int f, const float *feat, const 
   if (!attn_l || !attn_r || !grad_attn_l || !grad_attn_r) return DGNN_ERR_BAD_ARG;
   if (n > 0 && (!feat || !g_row || !g_col || !grad_feat)) return DGNN_ERR_BAD_ARG;
   ScoreShape s;
-  if (!score_shape(h, f, feat, attn_l, attn_r, &s)) return DGNN_ERR_UNSUPPORTED;
-  if (s.vec == 4 && ((uintptr_t)grad_feat & 15)) s.vec = 1, s.G = 1;
-  if (s.vec == 1) {            // recompute the lane layout for the scalar path
-    if (f > 64) return DGNN_ERR_UNSUPPORTED;
-    s.G = 1;
-    while (s.G < f) s.G <<= 1;
-    s.spw = 64 / s.G;
-  }
+  const long long segs = (long long)n * h;
+  // a misaligned grad_feat takes the scalar layout (pass it as the alignment witness)
+  if (!score_shape(segs, h, f, ((uintptr_t)grad_feat & 15) ? (const void *)1 : feat, attn_l, attn_r, &s))
+    return DGNN_ERR_UNSUPPORTED;
   if (workspace_bytes < dgnn_gat_attn_scores_backward_workspace_bytes(n, h, f) || !workspace)
     return DGNN_ERR_WORKSPACE;
   if ((uintptr_t)workspace & 15) return DGNN_ERR_ALIGNMENT;
   hipStream_t st = (hipStream_t)stream;
   float *partial = (float *)workspace;
-  const long long segs = (long long)n * h;
   const dim3 grid((unsigned)blocks_for_waves(s.nw)), block(DGNN_BLOCK);
   if (s.vec == 4)
     hipLaunchKernelGGL(k_attn_scores_bwd<4>, grid, block, 0, st, segs, h, f, s.G, s.nw, feat, attn_l, attn_r,
@@ -297,7 +312,7 @@ int dgnn_gat_attn_scores_backward(int n, int h, int f, const float *feat, const 
     hipLaunchKernelGGL(k_attn_scores_bwd<1>, grid, block, 0, st, segs, h, f, s.G, s.nw, feat, attn_l, attn_r,
                        g_row, g_col, grad_feat, partial);
   DGNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_attn_scores_bwd_reduce, dim3((2 * h * f + 127) / 128), dim3(128), 0, st, h, f, s.G,
+  hipLaunchKernelGGL(k_attn_scores_bwd_reduce, dim3((unsigned)blocks_for_waves(2 * h * f)), dim3(DGNN_BLOCK), 0, st, h, f, s.G,
                      s.nw, s.vec, (const float *)partial, grad_attn_l, grad_attn_r);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
@@ -327,7 +342,7 @@ int dgnn_gat_epilogue(int n, int hf, int activation, float act_param, const floa
 
 size_t dgnn_gat_epilogue_backward_workspace_bytes(int n, int hf) {
   if (n < 0 || hf <= 0) return 0;
-  return sizeof(float) * (size_t)epi_threads(hf);
+  return sizeof(float) * (size_t)epi_threads_max(hf);
 }
 
 int dgnn_gat_epilogue_backward(int n, int hf, int activation, float act_param, const float *out,
@@ -343,7 +358,7 @@ int dgnn_gat_epilogue_backward(int n, int hf, int activation, float act_param, c
     }
     return DGNN_OK;
   }
-  const long long tt = epi_threads(hf);
+  const long long tt = epi_threads(n, hf);
   if (grad_bias && (!workspace || workspace_bytes < sizeof(float) * (size_t)tt)) return DGNN_ERR_WORKSPACE;
   const long long total = (long long)n * hf;
   const float *y = activation != 0 ? out : grad;      // unused by act_bwd when activation == 0
@@ -352,7 +367,7 @@ int dgnn_gat_epilogue_backward(int n, int hf, int activation, float act_param, c
                      grad_bias ? (float *)workspace : nullptr);
   DGNN_LAUNCH_CHECK();
   if (grad_bias) {
-    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3((hf + 127) / 128), dim3(128), 0, st, hf, tt,
+    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3((unsigned)blocks_for_waves(hf)), dim3(DGNN_BLOCK), 0, st, hf, tt,
                        (const float *)workspace, grad_bias);
     DGNN_LAUNCH_CHECK();
   }

@@ -61,11 +61,13 @@ def main():
                 negative_slope=args.negative_slope).to(device)
     loss_fcn = nn.CrossEntropyLoss()
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
-    feats, labels, train_mask = data["features"], data["labels"], data["train_mask"]
+    feats, labels = data["features"], data["labels"]
+    train_idx = data["train_mask"].nonzero().squeeze(1)      # index list: no host sync inside the epoch
+    train_labels = labels[train_idx]
     losses = []
 
     def train_epoch():
-        loss = loss_fcn(model(feats)[train_mask], labels[train_mask])
+        loss = loss_fcn(model(feats)[train_idx], train_labels)
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
