@@ -218,8 +218,9 @@ int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negati
                      size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
-  if (!attn_row || !attn_col || !row_ptr || !in_feat || !out_feat || !edge_max || !edge_sum)
-    return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;                          // nothing to write
+  if (!attn_row || !row_ptr || !out_feat || !edge_max || !edge_sum) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!attn_col || !in_feat)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && !col_ind) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
   if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
@@ -236,7 +237,9 @@ int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope, const
                        size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
-  if (!attn_row || !attn_col || !row_ptr || !in_feat || !out_feat) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (!attn_row || !row_ptr || !out_feat) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!attn_col || !in_feat)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && !col_ind) return DGNN_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
     return DGNN_ERR_WORKSPACE;
@@ -283,13 +286,13 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (n < 0) return DGNN_ERR_BAD_ARG;
-  if (!row_ptr || !col_ptr || !grad_attn_row) return DGNN_ERR_BAD_ARG;
-  if (m > 0 && (!edge_max || !edge_sum || !attn_row || !grad)) return DGNN_ERR_BAD_ARG;
+  if (!row_ptr || !col_ptr) return DGNN_ERR_BAD_ARG;
+  if (m > 0 && (!edge_max || !edge_sum || !attn_row || !grad || !grad_attn_row)) return DGNN_ERR_BAD_ARG;
   if (n > 0 && (!in_feat || !attn_col || !grad_feat || !grad_attn_col)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && (!col_ind || !row_ind || !permute)) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
   if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
-  const bool have_row_term = (out_feat != nullptr) || (row_dot != nullptr);
+  const bool have_row_term = (out_feat != nullptr) || (row_dot != nullptr) || m == 0;
   BwdLayout w = bwd_layout(m, n, nnz, h, f, !have_row_term);
   if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -399,8 +402,8 @@ int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *c
                   size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
-  if (!row_ptr || !in_feat || !out_feat || (nnz > 0 && (!col_ind || !edge_val))) return DGNN_ERR_BAD_ARG;
   if (m == 0) return DGNN_OK;
+  if (!row_ptr || !out_feat || (nnz > 0 && (!col_ind || !edge_val || !in_feat))) return DGNN_ERR_BAD_ARG;
   if (fwd_fast_ok(m, h)) {
     GatherParams P = {};
     P.m = m; P.nnz = nnz; P.H = h; P.F = f;
@@ -428,9 +431,9 @@ int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const 
   int rc = check_dims(nodes, nnz, kernels, embed);
   if (rc) return rc;
   if (dim <= 0) return DGNN_ERR_BAD_ARG;
-  if (!csr_ptr || !node_feat || !mu || !inv_sigma || !out || (nnz > 0 && (!col_ind || !pseudo)))
-    return DGNN_ERR_BAD_ARG;
   if (nodes == 0) return DGNN_OK;
+  if (!csr_ptr || !mu || !inv_sigma || !out || (nnz > 0 && (!col_ind || !pseudo || !node_feat)))
+    return DGNN_ERR_BAD_ARG;
   if (fwd_fast_ok(nodes, kernels)) {
     GatherParams P = {};
     P.m = nodes; P.nnz = nnz; P.H = kernels; P.F = embed; P.dim = dim;

@@ -367,3 +367,31 @@ def test_knn_feeds_edgeconv_like_the_reference_model():
     hs, hd = conv.theta(h), conv.phi(h) - conv.theta(h)
     want = (hs[src.long()].view(-1, k, 16) + hd[:, None, :]).max(1).values
     assert torch.allclose(out, want, rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- degenerate sizes
+@pytest.mark.parametrize("n", [0, 1, 7])
+@pytest.mark.parametrize("h,f", [(4, 64), (3, 6)])
+def test_graph_without_edges(nat, n, h, f):
+    """Every row empty (fused_gatconv_kernel.cu:45,66,90: edge_max = -1e38, edge_sum = 0, out = 0)
+    and the zero-node graph: defined results, no launch with an empty grid."""
+    row_ptr = torch.zeros(n + 1, dtype=torch.int32, device=DEV)
+    empty_i = torch.zeros(0, dtype=torch.int32, device=DEV)
+    x = torch.randn((n, h, f), device=DEV)
+    ar, ac = torch.randn((n, h), device=DEV), torch.randn((n, h), device=DEV)
+    grad = torch.randn((n, h, f), device=DEV)
+    out, emax, esum, emask = nat["gat"].gat_forward(ar, ac, row_ptr, empty_i, 0.2, x, 0.0)
+    assert out.shape == (n, h, f) and torch.all(out == 0)
+    assert torch.all(emax == np.float32(-1e38)) and torch.all(esum == 0)
+    assert torch.all(nat["gat"].gat_inference(ar, ac, row_ptr, empty_i, 0.2, x) == 0)
+    gf, gr, gc = nat["gat"].gat_backward(0.2, 0.0, row_ptr, empty_i, row_ptr, empty_i, empty_i, emax, esum,
+                                         emask, x, ar, ac, grad, out_feat=out)
+    assert torch.all(gf == 0) and torch.all(gr == 0) and torch.all(gc == 0)
+    gf, gr, gc = nat["gat"].gat_backward(0.2, 0.0, row_ptr, empty_i, row_ptr, empty_i, empty_i, emax, esum,
+                                         emask, x, ar, ac, grad)          # reference signature
+    assert torch.all(gf == 0) and torch.all(gr == 0) and torch.all(gc == 0)
+    val = torch.zeros((0, h), device=DEV)
+    assert torch.all(nat["spmm"].spmm_csr(row_ptr, empty_i, val, x) == 0)
+    assert nat["sddmm"].mhsddmm(row_ptr, empty_i, grad, x).shape == (0, h)
+    cp, ri, pm = nat["fmt"].csr2csc_int(row_ptr, empty_i)
+    assert cp.tolist() == [0] * (n + 1) and ri.numel() == 0 and pm.numel() == 0
