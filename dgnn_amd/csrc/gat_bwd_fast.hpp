@@ -31,8 +31,9 @@ namespace dgnn {
 
 struct BwdParams {
   int n, m, nnz, H, F, HF, L, T;
-  int rowv;            // HF/4 float4 slots per feature row (<= 64)
-  int fv;              // F/4 lanes per head (power of two)
+  int vec;             // floats per lane load: 4 (F % 4 == 0, 16-byte aligned rows) or 1
+  int fv;              // lanes per head: power of two >= ceil(F/vec), <= 64
+  int hpp;             // heads per lane pass = 64 / fv; ceil(H / hpp) passes walk the stream
   int slot_stride;     // HF + H rounded up to 4
   float attn_drop, slope;
   const int *col_ptr, *row_ind, *permute;
@@ -57,28 +58,66 @@ static inline size_t bwd_lds_bytes(int H, int L) {
   return (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)L * H * 2 + (size_t)L * 5) * sizeof(float);
 }
 
+// Lane -> (head, feature slice) map shared by the backward kernels: in the pass that starts at
+// head hb, head hb+g owns the aligned group of fv lanes [g*fv, (g+1)*fv); lane q of the group
+// holds features [q*VEC, q*VEC+VEC) of the head, lanes past F idle.  Any (H <= 8, F) fits: a
+// 4 x 64 row is one pass, 1 x 47 one pass of scalar lanes, 4 x 41 four passes of one head each;
+// a pass gathers only its own heads' slice of every row, so no byte is read twice, and the
+// per-head reductions stay inside aligned power-of-two lane groups (DPP).
+struct BwdLane {
+  bool active, leader;
+  int head;
+  size_t off;          // float offset of the lane's slice inside a feature row
+};
+template <int VEC>
+__device__ __forceinline__ BwdLane bwd_lane(const BwdParams &P, int lane, int hb) {
+  BwdLane m;
+  const int head = hb + lane / P.fv, q = lane % P.fv;
+  m.active = head < P.H && q * VEC < P.F;
+  m.head = m.active ? head : 0;
+  m.off = m.active ? (size_t)head * P.F + (size_t)q * VEC : 0;
+  m.leader = m.active && q == 0;
+  return m;
+}
+template <int VEC>
+__device__ __forceinline__ float vec_dot(const typename VecT<VEC>::type &a, const typename VecT<VEC>::type &b);
+template <>
+__device__ __forceinline__ float vec_dot<4>(const float4 &a, const float4 &b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+template <>
+__device__ __forceinline__ float vec_dot<1>(const float &a, const float &b) { return a * b; }
+template <int VEC>
+__device__ __forceinline__ void vec_add(typename VecT<VEC>::type &a, const typename VecT<VEC>::type &b);
+template <>
+__device__ __forceinline__ void vec_add<4>(float4 &a, const float4 &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+template <>
+__device__ __forceinline__ void vec_add<1>(float &a, const float &b) { a += b; }
+
 // Per destination row: S[r,h] = <grad[r,h,:], out[r,h,:]> and the packed statistics the CSC pass
-// gathers with one 16-byte load per (edge, head).  One wave per row, float4 per lane.
+// gathers with one 16-byte load per (edge, head).  One wave per row.
+template <int VEC>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
+  using vec_t = typename VecT<VEC>::type;
   const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
   if (r >= P.m) return;
-  const int lane = lane_id();
-  const bool active = lane < P.rowv;
-  const int head = active ? (lane * 4) / P.F : 0;
-  float s = 0.f;
-  if (P.S_in == nullptr) {
-    if (active) {
-      const float4 g = *(const float4 *)(P.grad + (size_t)r * P.HF + (size_t)lane * 4);
-      const float4 o = *(const float4 *)(P.out_feat + (size_t)r * P.HF + (size_t)lane * 4);
-      s = fmaf(g.x, o.x, fmaf(g.y, o.y, fmaf(g.z, o.z, g.w * o.w)));
+  for (int hb = 0; hb < P.H; hb += P.hpp) {
+    const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
+    float s = 0.f;
+    if (P.S_in == nullptr) {
+      if (ln.active) {
+        const vec_t g = *(const vec_t *)(P.grad + (size_t)r * P.HF + ln.off);
+        const vec_t o = *(const vec_t *)(P.out_feat + (size_t)r * P.HF + ln.off);
+        s = vec_dot<VEC>(g, o);
+      }
+      s = group_reduce(s, P.fv, OpSum());
+    } else if (ln.active) {
+      s = P.S_in[(size_t)r * P.H + ln.head];
     }
-    s = group_reduce(s, P.fv, OpSum());
-  } else if (active) {
-    s = P.S_in[(size_t)r * P.H + head];
-  }
-  if (active && (lane % P.fv) == 0) {
-    const size_t i = (size_t)r * P.H + head;
-    P.rowstat[i] = make_float4(P.attn_row[i], P.edge_max[i], P.edge_sum[i], s);
+    if (ln.leader) {
+      const size_t i = (size_t)r * P.H + ln.head;
+      P.rowstat[i] = make_float4(P.attn_row[i], P.edge_max[i], P.edge_sum[i], s);
+    }
   }
 }
 
@@ -97,21 +136,24 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
   }
 }
 
-// HC = heads (compile time), EPL = edges per lane; the group holds L = 64*EPL CSC entries.
+// HC = heads rounded up to 1, 2, 4 or 8 (compile time; P.H is the real count), EPL = edges per
+// lane; the group holds L = 64*EPL CSC entries.
 // The gathered row statistics stay in registers between staging and the coefficient pass, so
 // LDS keeps only 8 B per (edge, head): {signed weight, B} with d written over B afterwards.
-template <int HC, int EPL>
+template <int HC, int EPL, int VEC>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
+  using V = VecT<VEC>;
+  using vec_t = typename V::type;
   extern __shared__ __align__(16) float lds_raw[];
   constexpr int L = DGNN_WAVE * EPL;
-  constexpr int H = HC;
+  const int H = P.H;
   const int wib = wave_in_block();
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
-  constexpr size_t per_wave_floats = (size_t)L * H * 2 + (size_t)L * 5;
-  float2 *cell = (float2 *)(lds_raw + (size_t)wib * per_wave_floats);  // [L][H] {±w, B -> d}
-  unsigned *kof = (unsigned *)(cell + (size_t)L * H);                   // [L] column ordinal | END
+  constexpr size_t per_wave_floats = (size_t)L * HC * 2 + (size_t)L * 5;
+  float2 *cell = (float2 *)(lds_raw + (size_t)wib * per_wave_floats);  // [L][HC] {±w, B -> d}
+  unsigned *kof = (unsigned *)(cell + (size_t)L * HC);                  // [L] column ordinal | END
   int *colk = (int *)(kof + L);                                         // [L] column id of ordinal k
   int *dq = colk + L;                                                   // [L] flush destination of ordinal k
   unsigned *stream = (unsigned *)(dq + L);                              // [2L] load stream
@@ -133,7 +175,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     const int p = j * DGNN_WAVE + lane;
 #pragma unroll
     for (int h = 0; h < HC; ++h)
-      st[j][h] = (p < cnt) ? P.rowstat[(size_t)rid[j] * HC + h] : make_float4(0.f, 0.f, 1.f, 0.f);
+      st[j][h] = (p < cnt && h < H) ? P.rowstat[(size_t)rid[j] * H + h] : make_float4(0.f, 0.f, 1.f, 0.f);
   }
 
   // ---------------------------------------------------------------- columns of the group
@@ -179,21 +221,22 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       stream[p + k + 1] = (unsigned)rid[j] | (kk & DGNN_BWD_END);
       const int pos = (P.edge_mask != nullptr) ? P.permute[e0 + p] : 0;
       float ac[HC];
-      if (HC == 4) {
+      if (HC == 4 && H == 4) {
         const float4 a4 = *(const float4 *)(P.attn_col + (size_t)c * 4);
         ac[0] = a4.x; ac[1 % HC] = a4.y; ac[2 % HC] = a4.z; ac[3 % HC] = a4.w;
       } else {
 #pragma unroll
-        for (int h = 0; h < HC; ++h) ac[h] = P.attn_col[(size_t)c * HC + h];
+        for (int h = 0; h < HC; ++h) ac[h] = (h < H) ? P.attn_col[(size_t)c * H + h] : 0.f;
       }
 #pragma unroll
       for (int h = 0; h < HC; ++h) {
+        if (h >= H) break;
         const float4 s4 = st[j][h];                            // {attn_row, edge_max, edge_sum, S}
         const float e = leaky_relu(s4.x + ac[h], P.slope);
         const float a = expf(e - s4.y) / s4.z;                 // :747
         float w = a;
         if (P.edge_mask != nullptr) {
-          if (!(P.edge_mask[(size_t)pos * HC + h] > P.attn_drop)) w = 0.f;   // :738
+          if (!(P.edge_mask[(size_t)pos * H + h] > P.attn_drop)) w = 0.f;    // :738
           w = w / (1 - P.attn_drop);                                         // :749 (float divide)
         }
         const bool neg = e < 0.f;                                            // :953
@@ -205,67 +248,67 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   wave_lds_sync();
 
   // ---------------------------------------------------------------- pipelined gather stream
-  const bool active = lane < P.rowv;
-  const int head = active ? (lane * 4) / P.F : 0;
-  const size_t lane_off = (size_t)(active ? lane : 0) * 4;
-  const bool head_leader = active && (lane % P.fv) == 0;
   const int items = cnt + K;
-  float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dsum = 0.f;
-  int k = -1;
-  float4 ring[DGNN_FAST_U];
-#pragma unroll
-  for (int i = 0; i < DGNN_FAST_U; ++i) {
-    ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < items) {
-      const unsigned v = (unsigned)uniform_i32((int)stream[i]);
-      const float *base = (v & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
-      if (active) ring[i] = *(const float4 *)(base + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off);
-    }
-  }
-  for (int j = 0; j < items; j += DGNN_FAST_U) {
-#pragma unroll
+  for (int hb = 0; hb < H; hb += P.hpp) {   // one pass per block of heads (a single pass when H*fv <= 64)
+    const BwdLane ln = bwd_lane<VEC>(P, lane, hb);
+    const bool active = ln.active;
+    const int head = ln.head;
+    const size_t lane_off = ln.off;
+    const bool head_leader = ln.leader;
+    vec_t u = V::zero();
+    vec_t acc = V::zero();
+    float dsum = 0.f;
+    int k = -1;
+    vec_t ring[DGNN_FAST_U];
+  #pragma unroll
     for (int i = 0; i < DGNN_FAST_U; ++i) {
-      const int it = j + i;
-      if (it < items) {
-        const float4 x = ring[i];
-        const unsigned v = (unsigned)uniform_i32((int)stream[it]);
-        if (it + DGNN_FAST_U < items) {
-          const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
-          const float *base = (nv & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
-          if (active) ring[i] = *(const float4 *)(base + (size_t)(nv & DGNN_BWD_IDMASK) * P.HF + lane_off);
-        }
-        if (v & DGNN_BWD_UFLAG) {
-          u = x;
-          ++k;
-        } else {
-          const int p = it - (k + 1);
-          float2 *cp = cell + (size_t)p * HC + head;
-          const float2 wb = *cp;
-          const float w = fabsf(wb.x);
-          const float sl = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
-          float dot = fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
-          dot = group_reduce(dot, P.fv, OpSum());
-          const float d = fmaf(sl * w, dot, -wb.y);
-          acc.x = fmaf(w, x.x, acc.x);
-          acc.y = fmaf(w, x.y, acc.y);
-          acc.z = fmaf(w, x.z, acc.z);
-          acc.w = fmaf(w, x.w, acc.w);
-          dsum += d;
-          if (head_leader) cp->y = d;     // B is dead after this read: keep d in its place
-          if (v & DGNN_BWD_END) {
-            const int dst = uniform_i32(dq[k]);
-            if (dst >= 0) {
-              if (active) *(float4 *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
-              if (head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
-            } else {
-              float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
-              if (active) *(float4 *)(sp + lane_off) = acc;
-              if (head_leader) sp[P.HF + head] = dsum;
+      ring[i] = V::zero();
+      if (i < items) {
+        const unsigned v = (unsigned)uniform_i32((int)stream[i]);
+        const float *base = (v & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
+        if (active) ring[i] = *(const vec_t *)(base + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off);
+      }
+    }
+    for (int j = 0; j < items; j += DGNN_FAST_U) {
+  #pragma unroll
+      for (int i = 0; i < DGNN_FAST_U; ++i) {
+        const int it = j + i;
+        if (it < items) {
+          const vec_t x = ring[i];
+          const unsigned v = (unsigned)uniform_i32((int)stream[it]);
+          if (it + DGNN_FAST_U < items) {
+            const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
+            const float *base = (nv & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
+            if (active) ring[i] = *(const vec_t *)(base + (size_t)(nv & DGNN_BWD_IDMASK) * P.HF + lane_off);
+          }
+          if (v & DGNN_BWD_UFLAG) {
+            u = x;
+            ++k;
+          } else {
+            const int p = it - (k + 1);
+            float2 *cp = cell + (size_t)p * HC + head;
+            const float2 wb = *cp;
+            const float w = fabsf(wb.x);
+            const float sl = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
+            float dot = active ? vec_dot<VEC>(x, u) : 0.f;
+            dot = group_reduce(dot, P.fv, OpSum());
+            const float d = fmaf(sl * w, dot, -wb.y);
+            V::fma(acc, w, x);
+            dsum += d;
+            if (head_leader) cp->y = d;     // B is dead after this read: keep d in its place
+            if (v & DGNN_BWD_END) {
+              const int dst = uniform_i32(dq[k]);
+              if (dst >= 0) {
+                if (active) *(vec_t *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
+                if (head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
+              } else {
+                float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
+                if (active) *(vec_t *)(sp + lane_off) = acc;
+                if (head_leader) sp[P.HF + head] = dsum;
+              }
+              acc = V::zero();
+              dsum = 0.f;
             }
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            dsum = 0.f;
           }
         }
       }
@@ -279,20 +322,23 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     const int p = j * DGNN_WAVE + lane;
     if (p < cnt) {
       const size_t pos = (size_t)P.permute[e0 + p];
-      if (HC == 4) {
+      if (HC == 4 && H == 4) {
         *(float4 *)(P.dE + pos * 4) = make_float4(cell[(size_t)p * HC + 0].y, cell[(size_t)p * HC + 1 % HC].y,
                                                   cell[(size_t)p * HC + 2 % HC].y, cell[(size_t)p * HC + 3 % HC].y);
       } else {
 #pragma unroll
-        for (int h = 0; h < HC; ++h) P.dE[pos * HC + h] = cell[(size_t)p * HC + h].y;
+        for (int h = 0; h < HC; ++h)
+          if (h < H) P.dE[pos * H + h] = cell[(size_t)p * HC + h].y;
       }
     }
   }
 }
 
 // Merge the partial slots of columns cut by a group boundary (plain sums, fixed order).
+template <int VEC>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
-  const int lane = lane_id();
+  using V = VecT<VEC>;
+  using vec_t = typename V::type;
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) + 1;
   if (t >= P.T) return;
   const int L = P.L, H = P.H;
@@ -303,22 +349,22 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
   if (cs < edge - L) return;
   const int t_last = (ce - 1) / L;
   const int npieces = t_last - t + 2;
-  const bool active = lane < P.rowv;
-  const int head = active ? (lane * 4) / P.F : 0;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dsum = 0.f;
-  for (int i = 0; i < npieces; ++i) {
-    const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
-    const float *sp = P.slots + (size_t)s * P.slot_stride;
-    if (active) {
-      const float4 v = *(const float4 *)(sp + (size_t)lane * 4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      dsum += sp[P.HF + head];
+  for (int hb = 0; hb < H; hb += P.hpp) {
+    const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
+    vec_t acc = V::zero();
+    float dsum = 0.f;
+    for (int i = 0; i < npieces; ++i) {
+      const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
+      const float *sp = P.slots + (size_t)s * P.slot_stride;
+      if (ln.active) {
+        vec_add<VEC>(acc, *(const vec_t *)(sp + ln.off));
+        dsum += sp[P.HF + ln.head];
+      }
     }
-  }
-  if (active) {
-    *(float4 *)(P.grad_feat + (size_t)c * P.HF + (size_t)lane * 4) = acc;
-    if ((lane % P.fv) == 0) P.grad_attn_col[(size_t)c * H + head] = dsum;
+    if (ln.active) {
+      *(vec_t *)(P.grad_feat + (size_t)c * P.HF + ln.off) = acc;
+      if (ln.leader) P.grad_attn_col[(size_t)c * H + ln.head] = dsum;
+    }
   }
 }
 

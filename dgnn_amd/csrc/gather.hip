@@ -152,9 +152,19 @@ int rowsum_long_threshold() {
   return v;
 }
 
+// lanes per head of the backward's lane map (gat_bwd_fast.hpp: bwd_lane): power of two covering
+// ceil(f / vec) lanes
+int bwd_lanes_per_head(int f, int vec) {
+  const int need = (f + vec - 1) / vec;
+  int g = 1;
+  while (g < need) g <<= 1;
+  return g;
+}
+int bwd_heads_padded(int h) { return h <= 1 ? 1 : h <= 2 ? 2 : h <= 4 ? 4 : 8; }
 bool bwd_fast_shape(int m, int n, int h, int f) {
-  return !force_generic() && (h == 1 || h == 2 || h == 4 || h == 8) && (f % 4 == 0) &&
-         (h * f <= 256) && is_pow2(f / 4) && m < (1 << 30) && n < (1 << 30);
+  if (force_generic() || h > 8 || m >= (1 << 30) || n >= (1 << 30)) return false;
+  if (f > 256) return false;
+  return bwd_lanes_per_head(f, f % 4 == 0 ? 4 : 1) <= DGNN_WAVE;   // one head fits one lane pass
 }
 
 BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
@@ -169,7 +179,7 @@ BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
   w.off_long = o;                                // [0] = counter, [1..] = queue
   o += align_up(sizeof(int) * ((size_t)w.max_long + 1), 256);
   if (w.fast) {
-    w.L = bwd_group_size(h, nnz);
+    w.L = bwd_group_size(bwd_heads_padded(h), nnz);
     w.T = (nnz + w.L - 1) / w.L;
     w.slot_stride = (int)align_up((size_t)h * f + (size_t)h, 4);
     w.off_stat = o;
@@ -310,12 +320,17 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     if (rc) return rc;
     out = tmp;
   }
-  bool fast = w.fast && aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
-              aligned16(attn_col) && (out == nullptr || aligned16(out));
+  const int vec = (f % 4 == 0) ? 4 : 1;
+  // float4 row slices need 16-byte aligned tensors; H = 4 moves attn_col as float4 in any case
+  bool fast = w.fast && (h != 4 || aligned16(attn_col)) &&
+              (vec == 1 || (aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
+                            (out == nullptr || aligned16(out))));
   if (fast) {
     BwdParams P = {};
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
-    P.L = w.L; P.T = w.T; P.rowv = h * f / 4; P.fv = f / 4; P.slot_stride = w.slot_stride;
+    P.L = w.L; P.T = w.T; P.vec = vec; P.fv = bwd_lanes_per_head(f, vec); P.slot_stride = w.slot_stride;
+    P.hpp = DGNN_WAVE / P.fv;
+    const int hc = bwd_heads_padded(h);
     P.attn_drop = attn_drop; P.slope = negative_slope;
     P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
     P.attn_row = attn_row; P.attn_col = attn_col; P.edge_max = edge_max; P.edge_sum = edge_sum;
@@ -326,7 +341,10 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     P.task_col0 = (int *)(ws + w.off_cols);
     P.slots = (float *)(ws + w.off_slots);
     if (m > 0) {
-      hipLaunchKernelGGL(k_bwd_rowstat, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
+      if (vec == 4)
+        hipLaunchKernelGGL(k_bwd_rowstat<4>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
+      else
+        hipLaunchKernelGGL(k_bwd_rowstat<1>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
       DGNN_LAUNCH_CHECK();
     }
     if (n > 0) {
@@ -337,10 +355,14 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     }
     if (P.T > 0) {
       const dim3 grid(blocks_for_waves(P.T)), block(DGNN_BLOCK);
-      const size_t lds = bwd_lds_bytes(h, P.L) + (size_t)env_int("DGNN_BWD_LDS_PAD", 0);
+      const size_t lds = bwd_lds_bytes(hc, P.L) + (size_t)env_int("DGNN_BWD_LDS_PAD", 0);
 #define DGNN_BWD_CASE(HC, EPL)                                                              \
-  if (h == HC && P.L == 64 * EPL)                                                           \
-    hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL>), grid, block, lds, st, P);
+  if (hc == HC && P.L == 64 * EPL) {                                                        \
+    if (vec == 4)                                                                           \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4>), grid, block, lds, st, P);          \
+    else                                                                                    \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 1>), grid, block, lds, st, P);          \
+  }
       timer_mark(1, 0, st);
       DGNN_BWD_CASE(1, 1) DGNN_BWD_CASE(1, 2) DGNN_BWD_CASE(1, 4)
       DGNN_BWD_CASE(2, 1) DGNN_BWD_CASE(2, 2) DGNN_BWD_CASE(2, 4)
@@ -350,7 +372,10 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
       timer_mark(1, 1, st);
       DGNN_LAUNCH_CHECK();
       if (P.T > 1) {
-        hipLaunchKernelGGL(k_bwd_fixup, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+        if (vec == 4)
+          hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+        else
+          hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
         DGNN_LAUNCH_CHECK();
       }
     }

@@ -44,7 +44,9 @@ def nat():
                 tr=mhtranspose, fmt=format_conversion, spmm=spmm)
 
 
-HF_CASES = [(4, 64), (1, 64), (1, 16), (3, 6), (8, 32), (2, 100), (1, 47), (4, 128)]
+HF_CASES = [(4, 64), (1, 64), (1, 16), (3, 6), (8, 32), (2, 100), (1, 47), (4, 128),
+            (1, 48), (4, 12), (8, 7), (2, 30), (1, 7),     # padded lane groups of the fast backward
+            (4, 41), (6, 20), (8, 64), (2, 256), (5, 33)]  # several head passes / padded head counts
 
 
 @pytest.mark.parametrize("name", list(GRAPHS))
@@ -52,7 +54,7 @@ HF_CASES = [(4, 64), (1, 64), (1, 16), (3, 6), (8, 32), (2, 100), (1, 47), (4, 1
 @pytest.mark.parametrize("p", [0.0, 0.5])
 def test_gat_forward_backward(nat, name, h, f, p):
     g = GRAPHS[name]
-    if name == "rmat4k" and (h, f) not in [(4, 64), (1, 64), (3, 6), (4, 128)]:
+    if name == "rmat4k" and (h, f) not in [(4, 64), (1, 64), (3, 6), (4, 128), (1, 47), (2, 100), (8, 7), (4, 41), (5, 33)]:
         pytest.skip("large graph: headline shapes only")
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=11)
     mask = np.random.default_rng(5).random((g["nnz"], h), dtype=np.float32) if p > 0 else None

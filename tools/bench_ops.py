@@ -93,6 +93,28 @@ def layer(workload="products"):
                       "torch_chain_ms": round(t_plain, 3)}), flush=True)
 
 
+def shapes(workload="products"):
+    """Fused GAT forward / backward over head x feature shapes other than the headline 4 x 64:
+    output layers (1 head x n_classes) and odd widths."""
+    from dgnn_amd.native import fused_gatconv as fg
+    g = bench.build_graph(workload, dev)
+    n, nnz = g["n"], g["nnz"]
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    for H, F in ((1, 47), (1, 48), (1, 64), (1, 16), (8, 32), (2, 64), (4, 41), (4, 64)):
+        x = torch.rand((n, H, F), device=dev, generator=gen) - 0.4
+        ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
+        ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
+        go = torch.rand((n, H, F), device=dev, generator=gen) - 0.5
+        out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
+        tf = timeit(lambda: fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0), iters=3, warm=1)
+        tb = timeit(lambda: fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"],
+                                            emax, esum, emask, x, ar, ac, go, out_feat=out), iters=3, warm=1)
+        ab = bench.algorithmic_bytes(n, nnz, H, F)
+        print(json.dumps({"op": f"gat {workload}", "H": H, "F": F, "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
+                          "fwd_GBps": round(ab["fwd"] / tf / 1e6, 1), "bwd_GBps": round(ab["bwd_csc"] / tb / 1e6, 1)}), flush=True)
+        del x, go, out
+
+
 def gmm_pubmed():
     from dgnn_amd.operators import GmmConvFuse
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -147,4 +169,4 @@ if __name__ == "__main__":
     ap.add_argument("which", nargs="*", default=["edgeconv", "gmm", "reddit"])
     a = ap.parse_args()
     for w in a.which:
-        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn, "layer": layer}[w]()
+        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn, "layer": layer, "shapes": shapes}[w]()
