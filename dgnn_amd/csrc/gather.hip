@@ -96,10 +96,14 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   const size_t lds = fast_lds_bytes(P.H, P.L) + (size_t)env_int("DGNN_FWD_LDS_PAD", 0);
   const dim3 grid(blocks_for_waves(P.T));
   if (MODE == MODE_GAT) timer_mark(0, 0, st);
-  if (vec4)
-    hipLaunchKernelGGL((k_fast_row_gather<MODE, 4>), grid, dim3(DGNN_BLOCK), lds, st, P);
-  else
-    hipLaunchKernelGGL((k_fast_row_gather<MODE, 1>), grid, dim3(DGNN_BLOCK), lds, st, P);
+  // vector slots per lane: one walk over the edges for rows up to 64 / 128 / 256 slots
+  const int ns = P.rowv <= DGNN_WAVE ? 1 : P.rowv <= 2 * DGNN_WAVE ? 2 : 4;
+#define DGNN_FWD_CASE(VECV, NSV)                                                              \
+  if ((vec4 ? 4 : 1) == VECV && ns == NSV)                                                    \
+    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV>), grid, dim3(DGNN_BLOCK), lds, st, P);
+  DGNN_FWD_CASE(4, 1) DGNN_FWD_CASE(4, 2) DGNN_FWD_CASE(4, 4)
+  DGNN_FWD_CASE(1, 1) DGNN_FWD_CASE(1, 2) DGNN_FWD_CASE(1, 4)
+#undef DGNN_FWD_CASE
   if (MODE == MODE_GAT) timer_mark(0, 1, st);
   DGNN_LAUNCH_CHECK();
   if (P.T > 1) {

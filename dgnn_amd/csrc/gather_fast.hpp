@@ -119,7 +119,10 @@ struct VecT<1> {
   static __device__ __forceinline__ void div(float &a, float s) { a /= s; }
 };
 
-template <int MODE, int VEC>
+// NS = vector slots per lane: a lane pass covers 64*NS slots of the feature row, so rows wider
+// than 64 slots (8 x 64 as float4, 3 x 41 as scalars ...) are still gathered in ONE walk over the
+// group's edges instead of one walk per 64 slots.
+template <int MODE, int VEC, int NS>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) {
   using V = VecT<VEC>;
   using vec_t = typename V::type;
@@ -266,30 +269,44 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   wave_lds_sync();
 
   // ---------------------------------------------------------------- phase C: pipelined gather
-  const int nfb = (P.rowv + DGNN_WAVE - 1) / DGNN_WAVE;
+  const int span = DGNN_WAVE * NS;
+  const int nfb = (P.rowv + span - 1) / span;
+  // With a dropout mask a dropped (edge, head) has weight exactly 0: its lanes skip the load,
+  // so the dropped share of the feature traffic never leaves HBM (the reference loads the row
+  // and multiplies by 0, fused_gatconv_kernel.cu:95-117; identical for finite features).
+  const bool skip0 = (MODE == MODE_GAT) && (P.edge_mask != nullptr);
   for (int fb = 0; fb < nfb; ++fb) {
-    const int vslot = fb * DGNN_WAVE + lane;
-    const bool active = vslot < P.rowv;
-    const int head = active ? (vslot * VEC) / P.F : 0;
-    const size_t lane_off = (size_t)(active ? vslot : 0) * VEC;
-    const float *wbase = sc + head;
-    vec_t acc = V::zero();
-    vec_t ring[DGNN_FAST_U];
-    float wring[DGNN_FAST_U];
-    // With a dropout mask a dropped (edge, head) has weight exactly 0: its lanes skip the load,
-    // so the dropped share of the feature traffic never leaves HBM (the reference loads the row
-    // and multiplies by 0, fused_gatconv_kernel.cu:95-117; identical for finite features).
-    const bool skip0 = (MODE == MODE_GAT) && (P.edge_mask != nullptr);
+    bool active[NS];
+    size_t lane_off[NS];
+    const float *wbase[NS];
+    vec_t acc[NS];
+    vec_t ring[DGNN_FAST_U][NS];
+    float wring[DGNN_FAST_U][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int vslot = fb * span + s * DGNN_WAVE + lane;
+      active[s] = vslot < P.rowv;
+      const int head = active[s] ? (vslot * VEC) / P.F : 0;
+      lane_off[s] = (size_t)(active[s] ? vslot : 0) * VEC;
+      wbase[s] = sc + head;
+      acc[s] = V::zero();
+    }
     int q = 0;
 #pragma unroll
     for (int k = 0; k < DGNN_FAST_U; ++k) {
-      ring[k] = V::zero();
-      wring[k] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        ring[k][s] = V::zero();
+        wring[k][s] = 0.f;
+      }
       if (k < cnt) {
         const unsigned c = uniform_i32((int)(cidx[k] & ~DGNN_ROWEND));
-        wring[k] = wbase[(size_t)k * H];
-        if (active && !(skip0 && wring[k] == 0.f))
-          ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          wring[k][s] = wbase[s][(size_t)k * H];
+          if (active[s] && !(skip0 && wring[k][s] == 0.f))
+            ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+        }
       }
     }
     for (int j = 0; j < cnt; j += DGNN_FAST_U) {
@@ -297,25 +314,37 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       for (int k = 0; k < DGNN_FAST_U; ++k) {
         const int p = j + k;
         if (p < cnt) {
-          const vec_t x = ring[k];
-          const float w = wring[k];
+          vec_t x[NS];
+          float w[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            x[s] = ring[k][s];
+            w[s] = wring[k][s];
+          }
           const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
           if (p + DGNN_FAST_U < cnt) {
             const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
-            wring[k] = wbase[(size_t)(p + DGNN_FAST_U) * H];
-            if (active && !(skip0 && wring[k] == 0.f))
-              ring[k] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off);
-            else
-              ring[k] = V::zero();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              wring[k][s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
+              if (active[s] && !(skip0 && wring[k][s] == 0.f))
+                ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+              else
+                ring[k][s] = V::zero();
+            }
           }
-          V::fma(acc, w, x);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) V::fma(acc[s], w[s], x[s]);
           if (ci & DGNN_ROWEND) {
             const int d = uniform_i32(dq[q]);
             ++q;
             float *dst = (d >= 0) ? P.out + (size_t)d * P.HF
                                   : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
-            if (active) *(vec_t *)(dst + lane_off) = acc;
-            acc = V::zero();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
+              acc[s] = V::zero();
+            }
           }
         }
       }

@@ -46,7 +46,7 @@ def nat():
 
 HF_CASES = [(4, 64), (1, 64), (1, 16), (3, 6), (8, 32), (2, 100), (1, 47), (4, 128),
             (1, 48), (4, 12), (8, 7), (2, 30), (1, 7),     # padded lane groups of the fast backward
-            (4, 41), (6, 20), (8, 64), (2, 256), (5, 33)]  # several head passes / padded head counts
+            (4, 41), (6, 20), (8, 64), (2, 256), (5, 33), (8, 47)]  # several head passes / padded head counts
 
 
 @pytest.mark.parametrize("name", list(GRAPHS))
