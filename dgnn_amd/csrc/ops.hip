@@ -38,14 +38,34 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_row(int v, int H, int F,
 // Neighbour-grouped SDDMM (fast path): one wave64 per group of DGNN_SDDMM_L consecutive edges,
 // whatever rows it spans.  The row operand A[r] rides the same software-pipelined load stream
 // as the gathered B rows (a "U item" in front of the row's edges), each a fully coalesced
-// 16 B/lane load; the dot product reduces inside the F/4 lanes of a head with DPP row ops.
+// load; the dot product reduces inside the power-of-two lane group of a head with DPP row ops
+// (lane map and head passes as in the fused backward, gat_bwd_fast.hpp: any H <= 8 and F).
 // No binary search per edge (findRow, computeUtil.h:38-54): the group finds its first row once
 // with a 64-ary cooperative search.  Per-edge outputs are staged in LDS and stored coalesced.
 #define DGNN_SDDMM_L 256
 #define DGNN_SDDMM_U 4
 #define DGNN_SDDMM_UFLAG 0x80000000u
+template <int VEC>
+struct SdVec;
+template <>
+struct SdVec<4> {
+  using T = float4;
+  static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ float dot(const T &x, const T &u) {
+    return fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
+  }
+};
+template <>
+struct SdVec<1> {
+  using T = float;
+  static __device__ __forceinline__ T zero() { return 0.f; }
+  static __device__ __forceinline__ float dot(const T &x, const T &u) { return x * u; }
+};
+
+// NS = head slices per lane: one walk of the stream serves hpp*NS heads.
+template <int VEC, int NS>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H, int F, int HF,
-                                                           int rowv, int fv,
+                                                           int hpp, int fv,
                                                            const int *__restrict__ row_ptr,
                                                            const int *__restrict__ col_ind,
                                                            const float *__restrict__ A,
@@ -108,43 +128,67 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H
   for (int p = lane; p < cnt; p += DGNN_WAVE) stream[p + kof[p] + 1] = (unsigned)col_ind[e0 + p];
   wave_lds_sync();
 
-  const bool active = lane < rowv;
-  const int head = active ? (lane * 4) / F : 0;
-  const size_t lane_off = (size_t)(active ? lane : 0) * 4;
-  const bool head_leader = active && (lane % fv) == 0;
+  using V = SdVec<VEC>;
+  using vec_t = typename V::T;
   const int items = cnt + K;
-  float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-  int k = -1;
-  float4 ring[DGNN_SDDMM_U];
+  for (int hb = 0; hb < H; hb += hpp * NS) {      // one stream pass per block of heads
+    bool active[NS], head_leader[NS];
+    int head[NS];
+    size_t lane_off[NS];
+    vec_t u[NS];
+    const int q = lane % fv;
 #pragma unroll
-  for (int i = 0; i < DGNN_SDDMM_U; ++i) {
-    ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < items) {
-      const unsigned sv = (unsigned)uniform_i32((int)stream[i]);
-      const float *base = (sv & DGNN_SDDMM_UFLAG) ? A : B;
-      if (active) ring[i] = *(const float4 *)(base + (size_t)(sv & 0x7fffffffu) * HF + lane_off);
+    for (int s = 0; s < NS; ++s) {
+      const int hd = hb + s * hpp + lane / fv;
+      active[s] = hd < H && q * VEC < F;
+      head[s] = active[s] ? hd : 0;
+      lane_off[s] = active[s] ? (size_t)hd * F + (size_t)q * VEC : 0;
+      head_leader[s] = active[s] && q == 0;
+      u[s] = V::zero();
     }
-  }
-  for (int j = 0; j < items; j += DGNN_SDDMM_U) {
+    int k = -1;
+    vec_t ring[DGNN_SDDMM_U][NS];
 #pragma unroll
     for (int i = 0; i < DGNN_SDDMM_U; ++i) {
-      const int it = j + i;
-      if (it < items) {
-        const float4 x = ring[i];
-        const unsigned sv = (unsigned)uniform_i32((int)stream[it]);
-        if (it + DGNN_SDDMM_U < items) {
-          const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_SDDMM_U]);
-          const float *base = (nv & DGNN_SDDMM_UFLAG) ? A : B;
-          if (active) ring[i] = *(const float4 *)(base + (size_t)(nv & 0x7fffffffu) * HF + lane_off);
-        }
-        if (sv & DGNN_SDDMM_UFLAG) {
-          u = x;
-          ++k;
-        } else {
-          const int p = it - (k + 1);
-          float dot = fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
-          dot = group_reduce(dot, fv, OpSum());
-          if (head_leader) dbuf[(size_t)p * H + head] = dot;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ring[i][s] = V::zero();
+      if (i < items) {
+        const unsigned sv = (unsigned)uniform_i32((int)stream[i]);
+        const float *base = ((sv & DGNN_SDDMM_UFLAG) ? A : B) + (size_t)(sv & 0x7fffffffu) * HF;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          if (active[s]) ring[i][s] = *(const vec_t *)(base + lane_off[s]);
+      }
+    }
+    for (int j = 0; j < items; j += DGNN_SDDMM_U) {
+#pragma unroll
+      for (int i = 0; i < DGNN_SDDMM_U; ++i) {
+        const int it = j + i;
+        if (it < items) {
+          vec_t x[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) x[s] = ring[i][s];
+          const unsigned sv = (unsigned)uniform_i32((int)stream[it]);
+          if (it + DGNN_SDDMM_U < items) {
+            const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_SDDMM_U]);
+            const float *base = ((nv & DGNN_SDDMM_UFLAG) ? A : B) + (size_t)(nv & 0x7fffffffu) * HF;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+              if (active[s]) ring[i][s] = *(const vec_t *)(base + lane_off[s]);
+          }
+          if (sv & DGNN_SDDMM_UFLAG) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) u[s] = x[s];
+            ++k;
+          } else {
+            const int p = it - (k + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              float dot = active[s] ? V::dot(x[s], u[s]) : 0.f;
+              dot = group_reduce(dot, fv, OpSum());
+              if (head_leader[s]) dbuf[(size_t)p * H + head[s]] = dot;
+            }
+          }
         }
       }
     }
@@ -335,16 +379,25 @@ int dgnn_mhsddmm(int v, int f, int h, int nnz, const int *row_ptr, const int *co
   if (!row_ptr || (nnz > 0 && (!col_ind || !grad || !feature || !out))) return DGNN_ERR_BAD_ARG;
   if (v == 0 || nnz == 0) return DGNN_OK;
   const int hf = h * f;
-  const bool pow2 = (f % 4 == 0) && (((f / 4) & (f / 4 - 1)) == 0);
   const char *fg = getenv("DGNN_FORCE_GENERIC");
-  const bool fast = pow2 && hf <= 256 && h <= 8 && v < (1 << 30) && !(fg && fg[0] == '1') &&
-                    (((uintptr_t)grad | (uintptr_t)feature) & 15u) == 0;
+  // lanes per head: power of two covering ceil(f / vec) lanes; a head must fit one lane pass
+  const int vec = (f % 4 == 0 && (((uintptr_t)grad | (uintptr_t)feature) & 15u) == 0) ? 4 : 1;
+  int fv = 1;
+  while (fv < (f + vec - 1) / vec) fv <<= 1;
+  const bool fast = fv <= DGNN_WAVE && h <= 8 && v < (1 << 30) && !(fg && fg[0] == '1');
   if (fast) {
     const int T = (nnz + DGNN_SDDMM_L - 1) / DGNN_SDDMM_L;
     const size_t lds = (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)DGNN_SDDMM_L * 3 + (size_t)DGNN_SDDMM_L * h) * sizeof(float);
-    hipLaunchKernelGGL(k_sddmm_fast, dim3(blocks_for_waves(T)), dim3(DGNN_BLOCK), lds,
-                       (hipStream_t)stream, v, nnz, h, f, hf, hf / 4, f / 4, row_ptr, col_ind, grad,
-                       feature, out);
+    const int hpp = DGNN_WAVE / fv;
+    const int passes = (h + hpp - 1) / hpp;              // lane passes needed for all heads
+    const int ns = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
+#define DGNN_SDDMM_CASE(VECV, NSV)                                                                   \
+  if (vec == VECV && ns == NSV)                                                                      \
+    hipLaunchKernelGGL((k_sddmm_fast<VECV, NSV>), dim3(blocks_for_waves(T)), dim3(DGNN_BLOCK), lds,  \
+                       (hipStream_t)stream, v, nnz, h, f, hf, hpp, fv, row_ptr, col_ind, grad, feature, out);
+    DGNN_SDDMM_CASE(4, 1) DGNN_SDDMM_CASE(4, 2) DGNN_SDDMM_CASE(4, 4)
+    DGNN_SDDMM_CASE(1, 1) DGNN_SDDMM_CASE(1, 2) DGNN_SDDMM_CASE(1, 4)
+#undef DGNN_SDDMM_CASE
   } else {
     hipLaunchKernelGGL(k_sddmm_row, dim3(blocks_for_waves(v)), dim3(DGNN_BLOCK), 0,
                        (hipStream_t)stream, v, h, f, row_ptr, col_ind, grad, feature, out);

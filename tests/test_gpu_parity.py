@@ -194,7 +194,7 @@ def test_gat_linearity_and_row_stochasticity_at_scale(nat):
 
 
 @pytest.mark.parametrize("name", ["tiny", "er64", "deg_edges", "powerlaw256", "rmat4k"])
-@pytest.mark.parametrize("h,f", [(4, 64), (3, 20), (1, 8), (3, 64)])
+@pytest.mark.parametrize("h,f", [(4, 64), (3, 20), (1, 8), (3, 64), (3, 41), (1, 47), (8, 64), (5, 7), (2, 256)])
 def test_spmm_sddmm_transpose(nat, name, h, f):
     g = GRAPHS[name]
     G = gdev(g)
