@@ -45,7 +45,13 @@ struct BwdParams {
   float *grad_feat, *grad_attn_col;
   int *task_col0;
   float *slots;        // [2T][slot_stride]
+  // GMM mode (BWD_GMM): the edge weight is the Gaussian mixture weight of the edge's pseudo
+  // coordinates (CSR order, fetched through permute); dE receives the raw dots = grad_gauss
+  const float *pseudo, *mu, *inv_sigma;
+  int dim;
 };
+
+enum { BWD_GAT = 0, BWD_GMM = 1 };
 
 static inline int bwd_group_size(int H, int nnz) {
   const int dflt = H <= 4 ? 256 : 128;
@@ -129,7 +135,8 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
     if (lb == hb) {
       float *o = P.grad_feat + (size_t)c * P.HF;
       for (int i = 0; i < P.HF; ++i) o[i] = 0.f;
-      for (int h = 0; h < P.H; ++h) P.grad_attn_col[(size_t)c * P.H + h] = 0.f;
+      if (P.grad_attn_col != nullptr)
+        for (int h = 0; h < P.H; ++h) P.grad_attn_col[(size_t)c * P.H + h] = 0.f;
     } else {
       for (int t = (lb + P.L - 1) / P.L; t <= (hb - 1) / P.L; ++t) P.task_col0[t] = (int)c;
     }
@@ -140,7 +147,11 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
 // lane; the group holds L = 64*EPL CSC entries.
 // The gathered row statistics stay in registers between staging and the coefficient pass, so
 // LDS keeps only 8 B per (edge, head): {signed weight, B} with d written over B afterwards.
-template <int HC, int EPL, int VEC>
+// BMODE = BWD_GAT: the fused GAT backward above.  BWD_GMM: the same single pass for the fused
+// GMMConv backward (replaces mhsddmm + mhtranspose + gmmconv on the CSC,
+// dgNN/operators/fused_gmmconv.py:21-24): grad_node_feat[c,k,:] = sum_i w_ik grad[r_i,k,:] with
+// w_ik = Gaussian weight of edge i, and grad_gauss[permute[i],k] = <grad[r_i,k,:], node_feat[c,k,:]>.
+template <int HC, int EPL, int VEC, int BMODE>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   using V = VecT<VEC>;
   using vec_t = typename V::type;
@@ -175,7 +186,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     const int p = j * DGNN_WAVE + lane;
 #pragma unroll
     for (int h = 0; h < HC; ++h)
-      st[j][h] = (p < cnt && h < H) ? P.rowstat[(size_t)rid[j] * H + h] : make_float4(0.f, 0.f, 1.f, 0.f);
+      st[j][h] = (BMODE == BWD_GAT && p < cnt && h < H) ? P.rowstat[(size_t)rid[j] * H + h]
+                                                       : make_float4(0.f, 0.f, 1.f, 0.f);
   }
 
   // ---------------------------------------------------------------- columns of the group
@@ -219,6 +231,17 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       const int k = (int)(kk & DGNN_BWD_IDMASK);
       const int c = colk[k];
       stream[p + k + 1] = (unsigned)rid[j] | (kk & DGNN_BWD_END);
+      if (BMODE == BWD_GMM) {
+        const size_t pos = (size_t)P.permute[e0 + p];
+#pragma unroll
+        for (int h = 0; h < HC; ++h) {
+          if (h >= H) break;
+          const float w = gmm_weight(P.dim, P.pseudo + pos * P.dim, P.mu + (size_t)h * P.dim,
+                                     P.inv_sigma + (size_t)h * P.dim);
+          cell[(size_t)p * HC + h] = make_float2(w, 0.f);
+        }
+        continue;
+      }
       const int pos = (P.edge_mask != nullptr) ? P.permute[e0 + p] : 0;
       float ac[HC];
       if (HC == 4 && H == 4) {
@@ -292,7 +315,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
             const float sl = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
             float dot = active ? vec_dot<VEC>(x, u) : 0.f;
             dot = group_reduce(dot, P.fv, OpSum());
-            const float d = fmaf(sl * w, dot, -wb.y);
+            const float d = (BMODE == BWD_GMM) ? dot : fmaf(sl * w, dot, -wb.y);
             V::fma(acc, w, x);
             dsum += d;
             if (head_leader) cp->y = d;     // B is dead after this read: keep d in its place
@@ -300,11 +323,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
               const int dst = uniform_i32(dq[k]);
               if (dst >= 0) {
                 if (active) *(vec_t *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
-                if (head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
+                if (BMODE == BWD_GAT && head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
               } else {
                 float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
                 if (active) *(vec_t *)(sp + lane_off) = acc;
-                if (head_leader) sp[P.HF + head] = dsum;
+                if (BMODE == BWD_GAT && head_leader) sp[P.HF + head] = dsum;
               }
               acc = V::zero();
               dsum = 0.f;
@@ -358,12 +381,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
       const float *sp = P.slots + (size_t)s * P.slot_stride;
       if (ln.active) {
         vec_add<VEC>(acc, *(const vec_t *)(sp + ln.off));
-        dsum += sp[P.HF + ln.head];
+        if (P.grad_attn_col != nullptr) dsum += sp[P.HF + ln.head];
       }
     }
     if (ln.active) {
       *(vec_t *)(P.grad_feat + (size_t)c * P.HF + ln.off) = acc;
-      if (ln.leader) P.grad_attn_col[(size_t)c * H + ln.head] = dsum;
+      if (ln.leader && P.grad_attn_col != nullptr) P.grad_attn_col[(size_t)c * H + ln.head] = dsum;
     }
   }
 }

@@ -201,6 +201,24 @@ BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
   return w;
 }
 
+// One-pass CSC gather kernel of the padded head count hc, group size P.L and lane width vec.
+template <int BMODE>
+void launch_bwd_gather(const BwdParams &P, int hc, int vec, dim3 grid, dim3 block, size_t lds,
+                       hipStream_t st) {
+#define DGNN_BWD_CASE(HC, EPL)                                                                    \
+  if (hc == HC && P.L == 64 * EPL) {                                                              \
+    if (vec == 4)                                                                                 \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4, BMODE>), grid, block, lds, st, P);         \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 1, BMODE>), grid, block, lds, st, P);         \
+  }
+  DGNN_BWD_CASE(1, 1) DGNN_BWD_CASE(1, 2) DGNN_BWD_CASE(1, 4)
+  DGNN_BWD_CASE(2, 1) DGNN_BWD_CASE(2, 2) DGNN_BWD_CASE(2, 4)
+  DGNN_BWD_CASE(4, 1) DGNN_BWD_CASE(4, 2) DGNN_BWD_CASE(4, 4)
+  DGNN_BWD_CASE(8, 1) DGNN_BWD_CASE(8, 2)
+#undef DGNN_BWD_CASE
+}
+
 int check_dims(int m, int nnz, int h, int f) {
   if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
   if ((long long)h * f > (1 << 20)) return DGNN_ERR_UNSUPPORTED;
@@ -360,19 +378,8 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     if (P.T > 0) {
       const dim3 grid(blocks_for_waves(P.T)), block(DGNN_BLOCK);
       const size_t lds = bwd_lds_bytes(hc, P.L) + (size_t)env_int("DGNN_BWD_LDS_PAD", 0);
-#define DGNN_BWD_CASE(HC, EPL)                                                              \
-  if (hc == HC && P.L == 64 * EPL) {                                                        \
-    if (vec == 4)                                                                           \
-      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4>), grid, block, lds, st, P);          \
-    else                                                                                    \
-      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 1>), grid, block, lds, st, P);          \
-  }
       timer_mark(1, 0, st);
-      DGNN_BWD_CASE(1, 1) DGNN_BWD_CASE(1, 2) DGNN_BWD_CASE(1, 4)
-      DGNN_BWD_CASE(2, 1) DGNN_BWD_CASE(2, 2) DGNN_BWD_CASE(2, 4)
-      DGNN_BWD_CASE(4, 1) DGNN_BWD_CASE(4, 2) DGNN_BWD_CASE(4, 4)
-      DGNN_BWD_CASE(8, 1) DGNN_BWD_CASE(8, 2)
-#undef DGNN_BWD_CASE
+      launch_bwd_gather<BWD_GAT>(P, hc, vec, grid, block, lds, st);
       timer_mark(1, 1, st);
       DGNN_LAUNCH_CHECK();
       if (P.T > 1) {
@@ -445,6 +452,77 @@ int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *c
                      (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, in_feat,
                      out_feat);
   DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+// ----------------------------------------------------------------- fused GMMConv backward
+// The one-pass GMM backward pays off when all kernels fit ONE lane pass (K * lanes-per-kernel
+// <= 64: 3 x 64, 2 x 100 ...); with several passes (3 x 41 scalar lanes) the SDDMM + CSC-gather
+// sequence, whose kernels hold several slices per lane, is faster (measured on the Reddit shape).
+static bool gmm_backward_fused_shape(int nodes, int kernels, int embed) {
+  if (!bwd_fast_shape(nodes, nodes, kernels, embed)) return false;
+  return kernels * bwd_lanes_per_head(embed, embed % 4 == 0 ? 4 : 1) <= DGNN_WAVE;
+}
+
+size_t dgnn_gmm_backward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
+  if (nodes < 0 || nnz < 0 || kernels <= 0 || embed <= 0) return 0;
+  if (!gmm_backward_fused_shape(nodes, kernels, embed)) return 0;
+  const int L = bwd_group_size(bwd_heads_padded(kernels), nnz);
+  const size_t T = ((size_t)nnz + L - 1) / L;
+  const size_t stride = align_up((size_t)kernels * embed + kernels, 4);
+  return align_up(sizeof(int) * (T > 0 ? T : 1), 256) + align_up(sizeof(float) * 2 * T * stride, 256);
+}
+
+int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
+                      const int *row_ind, const int *permute, const float *node_feat,
+                      const float *pseudo, const float *mu, const float *inv_sigma,
+                      const float *grad, float *grad_node_feat, float *grad_gauss,
+                      void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = check_dims(nodes, nnz, kernels, embed);
+  if (rc) return rc;
+  if (dim <= 0) return DGNN_ERR_BAD_ARG;
+  if (nodes == 0) return DGNN_OK;
+  if (!col_ptr || !mu || !inv_sigma || !grad_node_feat) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!row_ind || !permute || !node_feat || !pseudo || !grad || !grad_gauss))
+    return DGNN_ERR_BAD_ARG;
+  if (!gmm_backward_fused_shape(nodes, kernels, embed)) return DGNN_ERR_UNSUPPORTED;
+  const int vec = (embed % 4 == 0) ? 4 : 1;
+  if (vec == 4 && !(aligned16(node_feat) && aligned16(grad) && aligned16(grad_node_feat)))
+    return DGNN_ERR_UNSUPPORTED;
+  const size_t need = dgnn_gmm_backward_workspace_bytes(nodes, nnz, kernels, embed);
+  if (!workspace || workspace_bytes < need) return DGNN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  BwdParams P = {};
+  P.n = nodes; P.m = nodes; P.nnz = nnz; P.H = kernels; P.F = embed; P.HF = kernels * embed;
+  const int hc = bwd_heads_padded(kernels);
+  P.L = bwd_group_size(hc, nnz);
+  P.T = (nnz + P.L - 1) / P.L;
+  P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
+  P.slot_stride = (int)align_up((size_t)kernels * embed + kernels, 4);
+  P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
+  P.in_feat = node_feat; P.grad = grad; P.grad_feat = grad_node_feat; P.grad_attn_col = nullptr;
+  P.dE = grad_gauss;
+  P.pseudo = pseudo; P.mu = mu; P.inv_sigma = inv_sigma; P.dim = dim;
+  P.task_col0 = (int *)workspace;
+  P.slots = (float *)((char *)workspace + align_up(sizeof(int) * (size_t)(P.T > 0 ? P.T : 1), 256));
+  {
+    long long g = ((long long)nodes + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_bwd_prep_cols, dim3((unsigned)g), dim3(256), 0, st, P);
+    DGNN_LAUNCH_CHECK();
+  }
+  if (P.T > 0) {
+    const dim3 grid(blocks_for_waves(P.T)), block(DGNN_BLOCK);
+    launch_bwd_gather<BWD_GMM>(P, hc, vec, grid, block, bwd_lds_bytes(hc, P.L), st);
+    DGNN_LAUNCH_CHECK();
+    if (P.T > 1) {
+      if (vec == 4)
+        hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+      else
+        hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+      DGNN_LAUNCH_CHECK();
+    }
+  }
   return DGNN_OK;
 }
 

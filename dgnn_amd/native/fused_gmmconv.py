@@ -54,3 +54,30 @@ def GaussianBp(pseudo, mu, inv_sigma, grad_out):
                                             L.stream_of(pseudo))
     L.check(rc, "dgnn_gaussian_backward")
     return [po, mo, so]
+
+
+def gmm_backward_fused(colptr, rowind, permute, node_feat, pseudo, mu, inv_sigma, grad_out):
+    """-> (grad_node_feat [nodes,K,embed], grad_gauss [E,K] in CSR order), or None when the shape
+    is outside the one-pass kernel's range.  Not a reference export: it stands for the
+    mhsddmm + mhtranspose + gmmconv(CSC) sequence of dgNN/operators/fused_gmmconv.py:21-24."""
+    L.i32(colptr, "colptr"), L.i32(rowind, "rowind"), L.i32(permute, "permute")
+    L.f32(node_feat, "node_feat", 3), L.f32(pseudo, "pseudo", 2), L.f32(grad_out, "grad_out", 3)
+    L.f32(mu, "mu", 2), L.f32(inv_sigma, "inv_sigma", 2)
+    nodes, nnz = colptr.size(0) - 1, rowind.size(0)
+    kernels, embed, dim = node_feat.size(1), node_feat.size(2), pseudo.size(1)
+    if grad_out.shape != node_feat.shape or pseudo.size(0) != nnz or node_feat.size(0) != nodes:
+        raise L.DgnnError("gmm_backward_fused: grad_out / node_feat / pseudo shapes disagree with the graph")
+    nb = L.lib().dgnn_gmm_backward_workspace_bytes(nodes, nnz, kernels, embed)
+    if nb == 0:
+        return None
+    with torch.cuda.device(node_feat.device):
+        grad_feat = torch.empty_like(node_feat)
+        grad_gauss = torch.empty((nnz, kernels), dtype=torch.float32, device=node_feat.device)
+        ws = L.workspace(nb, node_feat)
+        rc = L.lib().dgnn_gmm_backward(nodes, nnz, kernels, dim, embed, L.p(colptr), L.p(rowind), L.p(permute),
+                                       L.p(node_feat), L.p(pseudo), L.p(mu), L.p(inv_sigma), L.p(grad_out),
+                                       L.p(grad_feat), L.p(grad_gauss), L.p(ws), nb, L.stream_of(node_feat))
+    if rc == -2:
+        return None
+    L.check(rc, "dgnn_gmm_backward")
+    return grad_feat, grad_gauss

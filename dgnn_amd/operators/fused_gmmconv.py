@@ -31,8 +31,14 @@ class GmmFuseFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma = ctx.saved_tensors
         grad_out = grad_out.contiguous()
-        gaussian_grad = mhsddmm.mhsddmm(rowptr, colind, grad_out, node_feat)
-        pseudo_tran = mhtranspose.mhtranspose(permute, pseudo)
-        node_feat_grad = gmm.gmmconv(colptr, rowind, grad_out, pseudo_tran, mu, sigma)
+        # one gather pass over the CSC yields both the feature gradient and the Gaussian
+        # gradient; shapes outside its range take the reference's three-call sequence
+        fused = gmm.gmm_backward_fused(colptr, rowind, permute, node_feat, pseudo, mu, sigma, grad_out)
+        if fused is not None:
+            node_feat_grad, gaussian_grad = fused
+        else:
+            gaussian_grad = mhsddmm.mhsddmm(rowptr, colind, grad_out, node_feat)
+            pseudo_tran = mhtranspose.mhtranspose(permute, pseudo)
+            node_feat_grad = gmm.gmmconv(colptr, rowind, grad_out, pseudo_tran, mu, sigma)
         pseudo_out, mu_out, sigma_out = gmm.GaussianBp(pseudo, mu, sigma, gaussian_grad)
         return None, None, None, None, None, node_feat_grad, pseudo_out, mu_out, sigma_out

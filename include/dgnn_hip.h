@@ -209,6 +209,22 @@ int dgnn_csr2csc(int m, int n, int nnz, const int *row_ptr, const int *col_ind, 
 /* Sorted COO row indices -> row_ptr [m+1].  Replaces coo2csr_cuda(), convert_kernel.cu:51-59. */
 int dgnn_coo2csr(int m, int nnz, const int *coo_row, int *row_ptr, void *stream);
 
+/* Fused GMMConv backward in ONE gather pass over the CSC (square graph): grad_node_feat[c,k,:] =
+ * sum_i w_ik grad[r_i,k,:] with w_ik the Gaussian weight of CSC entry i (pseudo is in CSR nnz
+ * order and is read through permute), and grad_gauss[permute[i],k] = <grad[r_i,k,:],
+ * node_feat[c,k,:]> ([nnz,K], CSR order: the input of dgnn_gaussian_backward).  Replaces the
+ * mhsddmm + mhtranspose + gmmconv-on-CSC sequence of dgNN/operators/fused_gmmconv.py:21-24 (two
+ * feature gathers and a binary search per edge) by one gather.  Taken when all kernels fit one
+ * lane pass: K * P <= 64 with P = the power of two covering ceil(embed/4) lanes (embed lanes when
+ * embed % 4 != 0); otherwise DGNN_ERR_UNSUPPORTED / workspace size 0 and the caller keeps the
+ * three-call sequence, which is the faster one there. */
+size_t dgnn_gmm_backward_workspace_bytes(int nodes, int nnz, int kernels, int embed);
+int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
+                      const int *row_ind, const int *permute, const float *node_feat,
+                      const float *pseudo, const float *mu, const float *inv_sigma,
+                      const float *grad, float *grad_node_feat, float *grad_gauss,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* Exact k-nearest-neighbour graph per point cloud: x [batch, points, dim] -> src_ind
  * [batch*points*k], src_ind[r*k + t] = global id (cloud offset included) of the t-th nearest
  * point of r within r's cloud, r itself included, ascending distance, ties -> lower id: the

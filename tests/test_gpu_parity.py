@@ -230,7 +230,7 @@ def test_csr2csc_coo2csr_bit_exact(nat, name):
 
 
 @pytest.mark.parametrize("name", ["tiny", "er64", "powerlaw256", "rmat4k"])
-@pytest.mark.parametrize("k,d,f", [(3, 2, 64), (3, 2, 16), (2, 3, 10), (1, 1, 128)])
+@pytest.mark.parametrize("k,d,f", [(3, 2, 64), (3, 2, 16), (2, 3, 10), (1, 1, 128), (3, 2, 41), (5, 2, 8)])
 def test_gmm(nat, name, k, d, f):
     g = GRAPHS[name]
     G = gdev(g)
@@ -253,6 +253,22 @@ def test_gmm(nat, name, k, d, f):
     big = 1e-6 * max(1.0, np.sqrt(g["nnz"]))
     assert_close(host(mo), mo64, "mu grad", rtol=1e-4, atol=big)
     assert_close(host(so), so64, "inv_sigma grad", rtol=1e-4, atol=big)
+    # one-pass fused backward == the reference's mhsddmm + (mhtranspose, gmmconv on the CSC)
+    # (dgNN/operators/fused_gmmconv.py:21-24)
+    grad = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    fused = nat["gmm"].gmm_backward_fused(G["col_ptr"], G["row_ind"], G["permute"], dev(node_feat), dev(pseudo),
+                                          dev(mu), dev(inv_sigma), dev(grad))
+    if k * (1 << int(np.ceil(np.log2(max(1, -(-f // (4 if f % 4 == 0 else 1)))))) ) > 64:
+        assert fused is None, "several lane passes: the caller keeps the three-call sequence"
+        return
+    assert fused is not None
+    pseudo_csc = pseudo[g["permute"]]
+    want_feat = oracle.gmmconv_f64(g["col_ptr"], g["row_ind"], grad, pseudo_csc, mu, inv_sigma)
+    mass_feat = oracle.gmmconv_f64(g["col_ptr"], g["row_ind"], np.abs(grad), pseudo_csc, mu, inv_sigma)
+    assert_close(host(fused[0]), want_feat, "fused gmm backward: grad_node_feat", mass=mass_feat)
+    want_gauss = oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], grad, node_feat)
+    mass_gauss = oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], np.abs(grad), np.abs(node_feat))
+    assert_close(host(fused[1]), want_gauss, "fused gmm backward: grad_gauss", mass=mass_gauss)
 
 
 def test_gmm_autograd_operator(nat):
