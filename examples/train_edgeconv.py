@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--num-points", type=int, default=2048)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--n-epochs", type=int, default=20, help="timed iterations over one synthetic batch")
+    ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--output", default=None)
     args = ap.parse_args()
     print(args)
@@ -67,8 +69,8 @@ def main():
     torch.manual_seed(0)
     x = torch.randn((args.batch_size, args.num_points, 3), device=device)
     y = torch.randint(0, 40, (args.batch_size,), device=device)
-    model = Model(args.k, [64, 64, 128, 256], [1024, 512, 256], 40).to(device)   # :244
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    model = Model(args.k, [64, 64, 128, 256], [1024, 512, 256], 40, dropout_prob=args.dropout).to(device)   # :244
+    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)
     losses = []
 
     def train_iter():

@@ -39,6 +39,6 @@ def test_monet_example(tmp_path):
 
 def test_dgcnn_example(tmp_path):
     cols, first, last = run("train_edgeconv.py", "--batch-size", "4", "--num-points", "256", "--k", "10",
-                            "--n-epochs", "10", tmp_path=tmp_path)
+                            "--n-epochs", "20", "--lr", "0.01", "--dropout", "0", tmp_path=tmp_path)
     assert cols[0] == "train_edgeconv_dgnn_amd" and cols[1] == "4 10" and len(cols) == 6
     assert last < first

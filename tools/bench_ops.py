@@ -93,6 +93,9 @@ def layer(workload="products"):
                       "torch_chain_ms": round(t_plain, 3)}), flush=True)
 
 
+SHAPES = ((1, 47), (1, 48), (1, 64), (1, 16), (8, 32), (2, 64), (4, 41), (4, 64), (8, 64), (4, 128), (4, 256))
+
+
 def shapes(workload="products"):
     """Fused GAT forward / backward over head x feature shapes other than the headline 4 x 64:
     output layers (1 head x n_classes) and odd widths."""
@@ -100,7 +103,7 @@ def shapes(workload="products"):
     g = bench.build_graph(workload, dev)
     n, nnz = g["n"], g["nnz"]
     gen = torch.Generator(device=dev); gen.manual_seed(0)
-    for H, F in ((1, 47), (1, 48), (1, 64), (1, 16), (8, 32), (2, 64), (4, 41), (4, 64)):
+    for H, F in SHAPES:
         x = torch.rand((n, H, F), device=dev, generator=gen) - 0.4
         ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
         ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
