@@ -9,8 +9,9 @@ BASELINE.json's metric (edges/s), the HBM roofline of the dominant kernel and a 
 (the oracle's float32 restatement of the reference kernels, timed on the host cores).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same graph is row-partitioned
-across ranks with RCCL all-gathers of the boundary-node features (dgnn_amd/dist.py); the work
-is fixed, so scaling is "strong".
+across ranks; each step exchanges only the boundary rows a rank references (all-to-all over RCCL,
+or all-gathers with DGNN_DIST_MODE=allgather; dgnn_amd/dist.py); the work is fixed, so scaling is
+"strong".
 """
 import argparse
 import json
