@@ -98,11 +98,22 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   if (MODE == MODE_GAT) timer_mark(0, 0, st);
   // vector slots per lane: one walk over the edges for rows up to 64 / 128 / 256 slots
   const int ns = P.rowv <= DGNN_WAVE ? 1 : P.rowv <= 2 * DGNN_WAVE ? 2 : 4;
-#define DGNN_FWD_CASE(VECV, NSV)                                                              \
-  if ((vec4 ? 4 : 1) == VECV && ns == NSV)                                                    \
-    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV>), grid, dim3(DGNN_BLOCK), lds, st, P);
-  DGNN_FWD_CASE(4, 1) DGNN_FWD_CASE(4, 2) DGNN_FWD_CASE(4, 4)
-  DGNN_FWD_CASE(1, 1) DGNN_FWD_CASE(1, 2) DGNN_FWD_CASE(1, 4)
+  // all-heads-at-once softmax phase for 1 / 2 / 8 heads (per-head vectors need aligned tensors)
+  int ht = 0;
+  if (MODE == MODE_GAT && (P.H == 1 || P.H == 2 || P.H == 8) && aligned16(P.attn_row) &&
+      aligned16(P.attn_col) && aligned16(P.edge_mask) && aligned16(P.edge_max) && aligned16(P.edge_sum))
+    ht = P.H;
+#define DGNN_FWD_CASE(VECV, NSV, HTV)                                                          \
+  if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV)                                        \
+    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV>), grid, dim3(DGNN_BLOCK), lds, st, P);
+#define DGNN_FWD_CASES(HTV)                                                                    \
+  DGNN_FWD_CASE(4, 1, HTV) DGNN_FWD_CASE(4, 2, HTV) DGNN_FWD_CASE(4, 4, HTV)                   \
+  DGNN_FWD_CASE(1, 1, HTV) DGNN_FWD_CASE(1, 2, HTV) DGNN_FWD_CASE(1, 4, HTV)
+  DGNN_FWD_CASES(0)
+  if (MODE == MODE_GAT) {
+    DGNN_FWD_CASES(1) DGNN_FWD_CASES(2) DGNN_FWD_CASES(8)
+  }
+#undef DGNN_FWD_CASES
 #undef DGNN_FWD_CASE
   if (MODE == MODE_GAT) timer_mark(0, 1, st);
   DGNN_LAUNCH_CHECK();

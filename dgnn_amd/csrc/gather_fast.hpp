@@ -122,8 +122,43 @@ struct VecT<1> {
 // NS = vector slots per lane: a lane pass covers 64*NS slots of the feature row, so rows wider
 // than 64 slots (8 x 64 as float4, 3 x 41 as scalars ...) are still gathered in ONE walk over the
 // group's edges instead of one walk per 64 slots.
-template <int MODE, int VEC, int NS>
+// HT floats (one per head) moved as the widest vectors that fit: 1 -> scalar, 2 -> float2,
+// 8 -> two float4.  Works on global and LDS pointers alike.
+template <int HT>
+__device__ __forceinline__ void ld_heads(float (&d)[HT], const float *p) {
+  if (HT % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < HT / 4; ++i) {
+      const float4 v = ((const float4 *)p)[i];
+      d[4 * i] = v.x; d[(4 * i + 1) % HT] = v.y; d[(4 * i + 2) % HT] = v.z; d[(4 * i + 3) % HT] = v.w;
+    }
+  } else if (HT == 2) {
+    const float2 v = *(const float2 *)p;
+    d[0] = v.x; d[1 % HT] = v.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < HT; ++i) d[i] = p[i];
+  }
+}
+template <int HT>
+__device__ __forceinline__ void st_heads(float *p, const float (&d)[HT]) {
+  if (HT % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < HT / 4; ++i)
+      ((float4 *)p)[i] = make_float4(d[4 * i], d[(4 * i + 1) % HT], d[(4 * i + 2) % HT], d[(4 * i + 3) % HT]);
+  } else if (HT == 2) {
+    *(float2 *)p = make_float2(d[0], d[1 % HT]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < HT; ++i) p[i] = d[i];
+  }
+}
+
+// HT = compile-time head count of the all-heads-at-once softmax phase for 1, 2 or 8 heads
+// (0: run-time H; H == 4 keeps its own float4 path below).
+template <int MODE, int VEC, int NS, int HT>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) {
+  constexpr int HTA = HT > 0 ? HT : 1;     // array extent that is legal for HT == 0 too
   using V = VecT<VEC>;
   using vec_t = typename V::type;
   extern __shared__ __align__(16) float lds_raw[];
@@ -145,7 +180,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     const int c = P.col_ind[e0 + p];
     cidx[p] = (unsigned)c;
     if (MODE == MODE_GAT) {
-      if (H == 4) {
+      if (HT > 0) {
+        float tmp[HTA];
+        ld_heads<HTA>(tmp, P.attn_col + (size_t)c * HTA);
+        st_heads<HTA>(sc + (size_t)p * HTA, tmp);
+      } else if (H == 4) {
         *(float4 *)(sc + (size_t)p * 4) = *(const float4 *)(P.attn_col + (size_t)c * 4);
       } else {
         for (int h = 0; h < H; ++h) sc[(size_t)p * H + h] = P.attn_col[(size_t)c * H + h];
@@ -172,7 +211,53 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         const bool whole = (rs >= e0) && (re <= e1);
         const int slot = (rs < e0) ? 2 * t : 2 * t + 1;
         float *slot_ptr = P.slots + (size_t)slot * P.slot_stride;
-        if (MODE == MODE_GAT && H == 4 && (b - a) <= DGNN_WAVE) {
+        if (MODE == MODE_GAT && HT > 0 && (b - a) <= DGNN_WAVE) {
+          // the whole segment fits one wave pass: all HT heads at once (lane = edge)
+          const int p = a + lane;
+          const bool live = p < b;
+          float arow[HTA], e[HTA], mx[HTA], pe[HTA], sm[HTA];
+          ld_heads<HTA>(arow, P.attn_row + (size_t)r * HTA);
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) e[h] = DGNN_NEG_INIT;
+          if (live) {
+            float c[HTA];
+            ld_heads<HTA>(c, sc + (size_t)p * HTA);
+#pragma unroll
+            for (int h = 0; h < HTA; ++h) e[h] = leaky_relu(arow[h] + c[h], P.slope);
+          }
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) mx[h] = wave_max(e[h]);
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) pe[h] = live ? expf(e[h] - mx[h]) : 0.f;
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) sm[h] = wave_sum(pe[h]);
+          if (live) {
+            float w[HTA];
+#pragma unroll
+            for (int h = 0; h < HTA; ++h) w[h] = whole ? pe[h] / sm[h] : pe[h];              // :102
+            if (P.edge_mask != nullptr) {
+              float mk[HTA];
+              ld_heads<HTA>(mk, P.edge_mask + (size_t)(e0 + p) * HTA);
+#pragma unroll
+              for (int h = 0; h < HTA; ++h) {
+                if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
+                w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
+              }
+            }
+            st_heads<HTA>(sc + (size_t)p * HTA, w);
+          }
+          if (lane == 0) {
+            if (whole) {
+              if (P.edge_max != nullptr) {
+                st_heads<HTA>(P.edge_max + (size_t)r * HTA, mx);
+                st_heads<HTA>(P.edge_sum + (size_t)r * HTA, sm);
+              }
+            } else {
+              st_heads<HTA>(slot_ptr + P.HF, mx);
+              st_heads<HTA>(slot_ptr + P.HF + HTA, sm);
+            }
+          }
+        } else if (MODE == MODE_GAT && H == 4 && (b - a) <= DGNN_WAVE) {
           // common case: the whole segment fits one wave pass, all four heads at once
           const int p = a + lane;
           const bool live = p < b;
