@@ -19,6 +19,7 @@ CITATION_SHAPES = {
     "citeseer": (3327, 9104, 3703, 6),
     "pubmed": (19717, 88648, 500, 3),
     "reddit": (232965, 114615892, 602, 41),
+    "products": (2449029, 62000000, 100, 47),      # R-MAT of bench.py's headline shape
 }
 
 
@@ -40,12 +41,17 @@ def synthetic_citation(name, device, seed=0):
     n, e, n_feats, n_classes = CITATION_SHAPES[name]
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    src = torch.randint(0, n, (e,), device=device, generator=gen)
-    dst = torch.randint(0, n, (e,), device=device, generator=gen)
-    keep = src != dst
-    loops = torch.arange(n, device=device)
-    src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
-    graph = prepare_graph(src, dst, n)
+    if name == "products":
+        import bench                               # skewed R-MAT graph, self loops included
+        g = bench.build_graph("products", device, seed)
+        graph = tuple(g[k] for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute"))
+    else:
+        src = torch.randint(0, n, (e,), device=device, generator=gen)
+        dst = torch.randint(0, n, (e,), device=device, generator=gen)
+        keep = src != dst
+        loops = torch.arange(n, device=device)
+        src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+        graph = prepare_graph(src, dst, n)
     features = torch.randn((n, n_feats), device=device, generator=gen)
     labels = torch.randint(0, n_classes, (n,), device=device, generator=gen)
     train_mask = torch.rand(n, device=device, generator=gen) < 0.3

@@ -36,7 +36,7 @@ class Net(nn.Module):
 
 def main():
     ap = argparse.ArgumentParser(description="GAT on dgnn_amd")
-    ap.add_argument("--dataset", default="cora", choices=["cora", "citeseer", "pubmed", "reddit"])
+    ap.add_argument("--dataset", default="cora", choices=["cora", "citeseer", "pubmed", "reddit", "products"])
     ap.add_argument("--gpu", type=int, default=0)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--weight-decay", type=float, default=5e-4)
