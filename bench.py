@@ -301,7 +301,7 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # a reported baseline of the N = 1 run only
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
     if use_pg:
