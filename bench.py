@@ -288,6 +288,24 @@ def main():
                 "bwd_kernel_GBps": round(ab["bwd_csc"] / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
                 "survey_3gather_model_GBps": round(ab["survey_total"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
+    if roof is None and (use_pg or args.force_dist):
+        # partitioned run: the same two kernels on this rank's blocks (forward on n_loc rows x
+        # nnz_fwd edges, backward on n_loc columns x nnz_bwd edges); rank 0's figures are reported
+        from dgnn_amd import _lib
+        step_fn()
+        torch.cuda.synchronize()
+        kf, kb = _lib.last_kernel_ms(0) or 0.0, _lib.last_kernel_ms(1) or 0.0
+        if kf > 0 and kb > 0:
+            bf = algorithmic_bytes(runner.n_loc, runner.nnz_fwd, H, F)["fwd"]
+            bb = algorithmic_bytes(runner.n_loc, runner.nnz_bwd, H, F)["bwd_csc"]
+            name, nbytes, ms = ("k_bwd_col_gather", bb, kb) if kb >= kf else ("k_fast_row_gather", bf, kf)
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": f"{name} on rank 0's block ({runner.n_loc} nodes, {runner.nnz_fwd} / "
+                              f"{runner.nnz_bwd} edges forward / backward)",
+                    "algorithmic_bytes": nbytes, "kernel_ms": round(ms, 3),
+                    "fwd_kernel_ms": round(kf, 3), "bwd_kernel_ms": round(kb, 3)}
     if rank == 0:
         line = {
             "metric": "GATConv fwd+bwd edges/s", "value": nnz / (ms_per_step * 1e-3), "unit": "edges/s",

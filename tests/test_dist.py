@@ -69,7 +69,7 @@ def check(parts, spec, h, f):
     assert_close(gc, gc64, "partitioned grad_attn_col", mass=m_gc)
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "allgather"), (3, "allgather")])
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (4, "halo"), (2, "allgather"), (3, "allgather")])
 def test_partitioned_gat_cpu_gloo(world, exchange):
     spec, h, f = (10, 700, 6000, 5), 2, 8
     check(run_world(world, "cpu", spec, h, f, exchange), spec, h, f)
