@@ -105,8 +105,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, 
         tile[e] = (j < jn && f0 + f < dim) ? xc[(size_t)(j0 + j) * dim + f0 + f] : 0.f;
       }
       wave_lds_sync();
-      // (two candidates at a time with packed-fp32 v_pk_fma_f32 was measured: no gain at 64 dims,
-      // 2.6x slower at 128 dims from the doubled query registers)
+      // (packed-fp32 v_pk_fma_f32 was measured twice: two candidates per instruction gave no gain
+      // at 64 dims and ran 2.6x slower at 128 dims from the doubled query registers; two dims of
+      // one candidate per instruction -- even/odd chains -- was 5-8 % slower than this scalar loop)
       for (int j = 0; j < jn; ++j) {
         float acc = (SINGLE || c == 0) ? 0.f : carry[j * 64 + lane];
         const float4 *cj = (const float4 *)(tile + j * FC);
