@@ -179,7 +179,6 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_bwd_col(
 // power-law graph the heavy rows sit next to each other, and a block lives as long as its
 // slowest 16-lane group) are queued and finished by one whole block each with a fixed reduction
 // tree.  Everything is a fixed-order sum: deterministic.
-#define DGNN_ROWSUM_LONG 4096
 #define DGNN_ROWSUM_R 4
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4(int m, const int *__restrict__ row_ptr,
                                                              const float4 *__restrict__ d4,
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4(int m, const int *_
 }
 
 // One block per queued hub row: 256 threads, 4 independent float4 loads per step, fixed LDS
-// tree.  The grid is sized for the worst case (nnz / DGNN_ROWSUM_LONG rows); spare blocks exit.
+// tree.  The grid is sized for the worst case (nnz / threshold rows); spare blocks exit.
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4_long(const int *__restrict__ row_ptr,
                                                                   const float4 *__restrict__ d4,
                                                                   float4 *__restrict__ grad_attn_row,
@@ -266,45 +265,62 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4_long(const int *__r
   if (threadIdx.x == 0) grad_attn_row[rr] = red[0];
 }
 
-// Any H: one 16-lane group per row.
+// Any H: one 16-lane group per row; rows above `long_thr` edges are queued for
+// k_gat_row_sum_long (one block per row), as in the H == 4 pair above.
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,
                                                             const int *__restrict__ row_ptr,
                                                             const float *__restrict__ dE,
-                                                            float *__restrict__ grad_attn_row) {
-  __shared__ float red[DGNN_BLOCK];
-  __shared__ int any_long;
+                                                            float *__restrict__ grad_attn_row,
+                                                            int *__restrict__ long_count,
+                                                            int *__restrict__ long_list, int long_thr) {
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
-  const int r0 = blockIdx.x * 16;
-  const int r = r0 + grp;
-  if (threadIdx.x == 0) any_long = 0;
-  __syncthreads();
-  if (r < m) {
-    const int lb = row_ptr[r], hb = row_ptr[r + 1];
-    if (hb - lb > DGNN_ROWSUM_LONG) {
-      if (q == 0) any_long = 1;
-    } else if (H <= 16 && (16 % H) == 0) {
-      // the 16 lanes walk the row's contiguous [deg*H] slab; since 16 % H == 0 a lane
-      // always lands on head q % H
+  const int r = blockIdx.x * 16 + grp;
+  if (r >= m) return;
+  const int lb = row_ptr[r], hb = row_ptr[r + 1];
+  if (hb - lb > long_thr) {
+    if (q == 0) long_list[atomicAdd(long_count, 1)] = r;
+    return;
+  }
+  if (H <= 16 && (16 % H) == 0) {
+    // the 16 lanes walk the row's contiguous [deg*H] slab; since 16 % H == 0 a lane always
+    // lands on head q % H
+    float s = 0.f;
+    const size_t beg = (size_t)lb * H, end = (size_t)hb * H;
+    for (size_t i = beg + q; i < end; i += 16) s += dE[i];
+    for (int st = H; st < 16; st <<= 1) s += __shfl_xor(s, st, 16);
+    if (q < H) grad_attn_row[(size_t)r * H + q] = s;
+  } else {
+    for (int h = q; h < H; h += 16) {
       float s = 0.f;
-      const size_t beg = (size_t)lb * H, end = (size_t)hb * H;
-      for (size_t i = beg + q; i < end; i += 16) s += dE[i];
-      for (int st = H; st < 16; st <<= 1) s += __shfl_xor(s, st, 16);
-      if (q < H) grad_attn_row[(size_t)r * H + q] = s;
-    } else {
-      for (int h = q; h < H; h += 16) {
-        float s = 0.f;
-        for (int p = lb; p < hb; ++p) s += dE[(size_t)p * H + h];
-        grad_attn_row[(size_t)r * H + h] = s;
-      }
+      for (int p = lb; p < hb; ++p) s += dE[(size_t)p * H + h];
+      grad_attn_row[(size_t)r * H + h] = s;
     }
   }
-  __syncthreads();
-  if (!any_long) return;
-  for (int g = 0; g < 16; ++g) {
-    const int rr = r0 + g;
-    if (rr >= m) break;
-    const int lb = row_ptr[rr], hb = row_ptr[rr + 1];
-    if (hb - lb <= DGNN_ROWSUM_LONG) continue;
+}
+
+// One block per queued long row, any H.  256 % H == 0: a thread keeps its head while striding
+// over the row's slab and the tree keeps heads apart down to stride H; other H: one tree per head.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum_long(int H, const int *__restrict__ row_ptr,
+                                                                 const float *__restrict__ dE,
+                                                                 float *__restrict__ grad_attn_row,
+                                                                 const int *__restrict__ long_count,
+                                                                 const int *__restrict__ long_list) {
+  __shared__ float red[DGNN_BLOCK];
+  if ((int)blockIdx.x >= *long_count) return;
+  const int rr = long_list[blockIdx.x];
+  const int lb = row_ptr[rr], hb = row_ptr[rr + 1];
+  if (H <= DGNN_BLOCK && (DGNN_BLOCK % H) == 0) {
+    float s = 0.f;
+    const size_t beg = (size_t)lb * H, end = (size_t)hb * H;
+    for (size_t i = beg + threadIdx.x; i < end; i += DGNN_BLOCK) s += dE[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = DGNN_BLOCK / 2; st >= H; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < H) grad_attn_row[(size_t)rr * H + threadIdx.x] = red[threadIdx.x];
+  } else {
     for (int h = 0; h < H; ++h) {
       float s = 0.f;
       for (int p = lb + (int)threadIdx.x; p < hb; p += DGNN_BLOCK) s += dE[(size_t)p * H + h];

@@ -417,11 +417,11 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     }
   }
   if (m > 0) {
+    int *long_count = (int *)(ws + w.off_long);
+    hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
     if (h == 4 && aligned16(dE) && aligned16(grad_attn_row)) {
       const int rows_per_block = 16 * DGNN_ROWSUM_R;
-      int *long_count = (int *)(ws + w.off_long);
-      hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int), st);
-      if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(k_gat_row_sum4, dim3((m + rows_per_block - 1) / rows_per_block),
                          dim3(DGNN_BLOCK), 0, st, m, row_ptr, (const float4 *)dE,
                          (float4 *)grad_attn_row, long_count, long_count + 1, rowsum_long_threshold());
@@ -431,7 +431,11 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
                          (const int *)(long_count + 1));
     } else {
       hipLaunchKernelGGL(k_gat_row_sum, dim3((m + 15) / 16), dim3(DGNN_BLOCK), 0, st, m, h, row_ptr,
-                         dE, grad_attn_row);
+                         dE, grad_attn_row, long_count, long_count + 1, rowsum_long_threshold());
+      DGNN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_gat_row_sum_long, dim3(w.max_long), dim3(DGNN_BLOCK), 0, st, h, row_ptr,
+                         (const float *)dE, grad_attn_row, (const int *)long_count,
+                         (const int *)(long_count + 1));
     }
     DGNN_LAUNCH_CHECK();
   }
