@@ -12,8 +12,8 @@
 namespace dgnn {
 namespace {
 
-constexpr int LAYER_WAVES = 2048;     // waves of the score kernels (partials are per wave)
-constexpr int EPI_BLOCKS = 512;       // blocks of the epilogue backward (partials per thread)
+constexpr int LAYER_WAVES = 8192;     // waves of the score kernels (partials are per wave)
+constexpr int EPI_BLOCKS = 2048;      // blocks of the epilogue backward (partials per thread)
 
 template <int VEC>
 struct Vec;
@@ -214,44 +214,59 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue4(long long total4, int 
   }
 }
 
-// grad_pre = grad * act'(y); every live thread walks ONE column (its stride is a multiple of hf)
-// and leaves its column sum in partial[tid].
-__global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue_bwd(long long total, long long tt, int act, float a,
+// grad_pre = grad * act'(y); every live thread walks ONE column slot of VEC columns (its stride
+// is a multiple of hf/VEC) and leaves its column sums in partial[tid*VEC ...].
+template <int VEC>
+__global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue_bwd(long long totalv, long long tt, int act, float a,
                                                              const float *__restrict__ y,
                                                              const float *__restrict__ grad,
                                                              float *__restrict__ grad_pre,
                                                              float *__restrict__ partial) {
+  using V = Vec<VEC>;
   const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (tid >= tt) return;
-  float acc = 0.f;
-  for (long long i = tid; i < total; i += tt) {
-    const float g = grad[i] * act_bwd(y[i], act, a);
-    grad_pre[i] = g;
-    acc += g;
+  float acc[VEC];
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) acc[c] = 0.f;
+  for (long long i = tid; i < totalv; i += tt) {
+    float g[VEC], o[VEC];
+    *(typename V::T *)g = V::load(grad + i * VEC);
+    *(typename V::T *)o = V::load(y + i * VEC);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      g[c] *= act_bwd(o[c], act, a);
+      acc[c] += g[c];
+    }
+    V::store(grad_pre + i * VEC, *(typename V::T *)g);
   }
-  if (partial) partial[tid] = acc;
+  if (partial) {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) partial[tid * VEC + c] = acc[c];
+  }
 }
-__global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue_bwd_reduce(int hf, long long tt,
+// one wave per bias column: the partials of the threads that walked the column's slot, in a
+// fixed lane pattern, then a fixed butterfly
+__global__ __launch_bounds__(DGNN_BLOCK) void k_epilogue_bwd_reduce(int hf, int vec, long long tt,
                                                                     const float *__restrict__ partial,
                                                                     float *__restrict__ grad_bias) {
   const int c = blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block();
   if (c >= hf) return;                               // wave-uniform exit
+  const int hfv = hf / vec, comp = c % vec;
   float acc = 0.f;
-  for (long long t = c + (long long)lane_id() * hf; t < tt; t += (long long)DGNN_WAVE * hf) acc += partial[t];
+  for (long long t = c / vec + (long long)lane_id() * hfv; t < tt; t += (long long)DGNN_WAVE * hfv)
+    acc += partial[t * vec + comp];
   acc = wave_sum(acc);
   if (lane_id() == 0) grad_bias[c] = acc;
 }
 
-// threads of k_epilogue_bwd: a multiple of hf (a thread keeps its column), ~8 rows per thread,
-// at most EPI_BLOCKS blocks worth
-static long long epi_threads_max(int hf) {
-  const long long cap = (long long)EPI_BLOCKS * DGNN_BLOCK;
-  return hf > cap ? hf : cap / hf * hf;
-}
-static long long epi_threads(int n, int hf) {
+// threads of k_epilogue_bwd: a multiple of the column slots hfv = hf/vec (a thread keeps its
+// slot), ~8 rows per thread, at most EPI_BLOCKS blocks worth
+static long long epi_threads(int n, int hfv) {
+  const long long cap_raw = (long long)EPI_BLOCKS * DGNN_BLOCK;
+  const long long cap = hfv > cap_raw ? hfv : cap_raw / hfv * hfv;
   long long rows = ((long long)n + 7) / 8;
   if (rows < 1) rows = 1;
-  const long long tt = rows * hf, cap = epi_threads_max(hf);
+  const long long tt = rows * hfv;
   return tt < cap ? tt : cap;
 }
 
@@ -342,7 +357,8 @@ int dgnn_gat_epilogue(int n, int hf, int activation, float act_param, const floa
 
 size_t dgnn_gat_epilogue_backward_workspace_bytes(int n, int hf) {
   if (n < 0 || hf <= 0) return 0;
-  return sizeof(float) * (size_t)epi_threads_max(hf);
+  const size_t cap = (size_t)EPI_BLOCKS * DGNN_BLOCK;      // thread slots, up to 4 floats each
+  return sizeof(float) * 4 * (cap > (size_t)hf ? cap : (size_t)hf);
 }
 
 int dgnn_gat_epilogue_backward(int n, int hf, int activation, float act_param, const float *out,
@@ -358,17 +374,25 @@ int dgnn_gat_epilogue_backward(int n, int hf, int activation, float act_param, c
     }
     return DGNN_OK;
   }
-  const long long tt = epi_threads(n, hf);
-  if (grad_bias && (!workspace || workspace_bytes < sizeof(float) * (size_t)tt)) return DGNN_ERR_WORKSPACE;
-  const long long total = (long long)n * hf;
+  auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+  const int vec = (hf % 4 == 0 && al16(out) && al16(grad) && al16(grad_pre)) ? 4 : 1;
+  const long long tt = epi_threads(n, hf / vec);
+  if (grad_bias && (!workspace || workspace_bytes < dgnn_gat_epilogue_backward_workspace_bytes(n, hf)))
+    return DGNN_ERR_WORKSPACE;
+  const long long totalv = (long long)n * hf / vec;
   const float *y = activation != 0 ? out : grad;      // unused by act_bwd when activation == 0
-  hipLaunchKernelGGL(k_epilogue_bwd, dim3((unsigned)((tt + DGNN_BLOCK - 1) / DGNN_BLOCK)), dim3(DGNN_BLOCK), 0,
-                     st, total, tt, activation, act_param, y, grad, grad_pre,
-                     grad_bias ? (float *)workspace : nullptr);
+  const dim3 grid((unsigned)((tt + DGNN_BLOCK - 1) / DGNN_BLOCK)), block(DGNN_BLOCK);
+  float *partial = grad_bias ? (float *)workspace : nullptr;
+  if (vec == 4)
+    hipLaunchKernelGGL(k_epilogue_bwd<4>, grid, block, 0, st, totalv, tt, activation, act_param, y, grad,
+                       grad_pre, partial);
+  else
+    hipLaunchKernelGGL(k_epilogue_bwd<1>, grid, block, 0, st, totalv, tt, activation, act_param, y, grad,
+                       grad_pre, partial);
   DGNN_LAUNCH_CHECK();
   if (grad_bias) {
-    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3((unsigned)blocks_for_waves(hf)), dim3(DGNN_BLOCK), 0, st, hf, tt,
-                       (const float *)workspace, grad_bias);
+    hipLaunchKernelGGL(k_epilogue_bwd_reduce, dim3((unsigned)blocks_for_waves(hf)), dim3(DGNN_BLOCK), 0, st, hf,
+                       vec, tt, (const float *)workspace, grad_bias);
     DGNN_LAUNCH_CHECK();
   }
   return DGNN_OK;
