@@ -6,10 +6,15 @@ Public API mirrors the reference package layout (dgNN/operators, dgNN/layers):
     from dgnn_amd.layers import GATConv, GMMConv, EdgeConv
 
 All compute runs in hand-written HIP kernels behind the C ABI of include/dgnn_hip.h
-(libdgnn_hip.so, loaded through ctypes).  There is no CPU fallback.
+(libdgnn_hip.so).  ``dgnn_amd/native/`` holds the PyTorch-ROCm C++ extension modules (pybind11,
+csrc/torch_binding.cpp) with the reference's top-level module names in front of that ABI.
+There is no CPU fallback.
 """
 import os
 import sys
+
+from . import _lib                      # noqa: F401  (DgnnError, the ctypes view of the C ABI)
+from ._lib import DgnnError             # noqa: F401
 
 __version__ = "0.1.0"
 

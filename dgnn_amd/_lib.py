@@ -1,9 +1,11 @@
-"""ctypes binding of ``libdgnn_hip.so`` (C ABI: ``include/dgnn_hip.h``).
+"""ctypes view of ``libdgnn_hip.so`` (C ABI: ``include/dgnn_hip.h``) and the error class of the
+package.
 
-PyTorch is plumbing here: it owns device memory (outputs and workspaces come from its
-caching allocator) and the current HIP stream; every operator runs in the hand-written HIP
-kernels behind the C ABI.  There is NO CPU or eager fallback: if the library is missing, or
-a tensor is not on a GPU, the call raises.
+The operators reach the library through the C++ extension modules of ``dgnn_amd/native/``
+(csrc/torch_binding.cpp); this module serves what needs the raw ABI from Python: the symbol /
+signature table the ABI tests check against the header, the workspace queries, and the
+kernel-timing hook bench.py reads (``last_kernel_ms``).  There is NO CPU or eager fallback: if
+the library is missing, or a tensor is not on a GPU, the call raises ``DgnnError``.
 """
 import ctypes
 import os

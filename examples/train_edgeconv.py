@@ -2,8 +2,13 @@
 """DGCNN classifier on the fused EdgeConv layer with the k-NN graph rebuilt in feature space
 before every layer (script/train/train_edgeconv.py: model :12-70, loss :73-79, CSV :288) on
 synthetic ModelNet40-shaped point clouds (batch x 2048 points x 3, 40 classes).  The DGL
-KNNGraph of the reference is replaced by dgnn_amd.layers.KNNGraph (csrc/knn.hip)."""
+KNNGraph of the reference is replaced by dgnn_amd.layers.KNNGraph (csrc/knn.hip).
+
+Under ``python -m torch.distributed.run --nproc-per-node N examples/train_edgeconv.py ...`` the
+batch is split over N GPUs, whole clouds per rank (dgnn_amd.dist.CloudDataParallel: the k-NN
+graph never crosses clouds, so only the weight gradients are all-reduced over RCCL)."""
 import argparse
+import os
 
 import torch
 import torch.nn.functional as F
@@ -64,12 +69,21 @@ def main():
     args = ap.parse_args()
     print(args)
 
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        args.gpu = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(args.gpu)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{args.gpu}"))
     device = torch.device(f"cuda:{args.gpu}")
     torch.cuda.set_device(device)
     torch.manual_seed(0)
     x = torch.randn((args.batch_size, args.num_points, 3), device=device)
     y = torch.randint(0, 40, (args.batch_size,), device=device)
     model = Model(args.k, [64, 64, 128, 256], [1024, 512, 256], 40, dropout_prob=args.dropout).to(device)   # :244
+    from dgnn_amd.dist import CloudDataParallel
+    dp = CloudDataParallel(model, args.batch_size, world, rank)
+    x, y = dp.local(x).contiguous(), dp.local(y).contiguous()      # this rank's clouds
     opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)
     losses = []
 
@@ -77,6 +91,7 @@ def main():
         loss = compute_loss(model(x), y)
         opt.zero_grad()
         loss.backward()
+        dp.reduce_gradients()
         opt.step()
         losses.append(loss.detach())
 
@@ -89,9 +104,17 @@ def main():
     model.eval()
     inference_time = time_epochs(infer_iter, args.n_epochs, warmup=0)
     acc = accuracy(infer_iter(), y)
-    print(f"loss {losses[0].item():.4f} -> {losses[-1].item():.4f}; accuracy on the batch {acc:.4f}")
-    append_csv(args.output, f"train_edgeconv_dgnn_amd,{args.batch_size} {args.k},{train_time}s,"
-                            f"{inference_time}s,{max_memory_mb(device)}MB,{acc}")
+    if world > 1:
+        t = torch.tensor([train_time, inference_time], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)               # the step ends when the slowest rank ends
+        train_time, inference_time = float(t[0]), float(t[1])
+    if rank == 0:
+        print(f"loss {losses[0].item():.4f} -> {losses[-1].item():.4f}; accuracy on the batch {acc:.4f}")
+        tag = f"{args.batch_size} {args.k}" + (f" dp{world}" if world > 1 else "")
+        append_csv(args.output, f"train_edgeconv_dgnn_amd,{tag},{train_time}s,"
+                                f"{inference_time}s,{max_memory_mb(device)}MB,{acc}")
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 The reference's autograd wrappers (dgNN/operators/*.py) import top-level native modules
 (`import fused_gatconv as fused_gat`, ...).  Here those module names are bound to stand-ins that
 (1) bind every call to the SIGNATURE of this repo's drop-in module of the same name
-(dgnn_amd/native/*.py) -- so a call the reference makes that our module could not accept fails
+(dgnn_amd/native/, csrc/torch_binding.cpp) -- so a call the reference makes that our module could not accept fails
 -- and (2) compute through the CPU oracle.  The reference wrappers are then driven forward and
 backward and compared with the float64 oracle: argument order, return lists and the positions
 of the `None` gradients (fused_gatconv.py:34, fused_gmmconv.py:27, fused_edgeconv.py:22) are
