@@ -30,6 +30,9 @@ namespace dgnn {
 #ifndef DGNN_FAST_U
 #define DGNN_FAST_U 3          // feature-row gathers in flight per wave (swept on MI355X: 1..16)
 #endif
+#ifndef DGNN_FWD_ROWCACHE
+#define DGNN_FWD_ROWCACHE 1
+#endif
 #define DGNN_FAST_HMAX 8
 #define DGNN_ROWEND 0x80000000u
 
@@ -204,8 +207,27 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   {
     int r = uniform_i32(P.task_row0[t]);
     int rs = uniform_i32(P.row_ptr[r]);
+#if DGNN_FWD_ROWCACHE
+    // Row ends (and, for four heads, the rows' own score terms) of 64 consecutive rows are
+    // fetched with ONE coalesced load per lane and handed out by v_readlane: a group of short
+    // rows no longer pays two dependent memory latencies per row.
+    int rbase = r;
+    int rp_c = P.row_ptr[min(rbase + 1 + lane, P.m)];
+    float4 ar_c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == MODE_GAT && HT == 0 && H == 4) ar_c = *(const float4 *)(P.attn_row + (size_t)min(rbase + lane, P.m - 1) * 4);
+#endif
     while (true) {
+#if DGNN_FWD_ROWCACHE
+      if (r - rbase == DGNN_WAVE) {
+        rbase = r;
+        rp_c = P.row_ptr[min(rbase + 1 + lane, P.m)];
+        if (MODE == MODE_GAT && HT == 0 && H == 4) ar_c = *(const float4 *)(P.attn_row + (size_t)min(rbase + lane, P.m - 1) * 4);
+      }
+      const int rk = r - rbase;
+      const int re = bcast_i32(rp_c, rk);
+#else
       const int re = uniform_i32(P.row_ptr[r + 1]);
+#endif
       const int a = max(rs, e0) - e0, b = min(re, e1) - e0;
       if (b > a) {
         const bool whole = (rs >= e0) && (re <= e1);
@@ -261,7 +283,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           // common case: the whole segment fits one wave pass, all four heads at once
           const int p = a + lane;
           const bool live = p < b;
+#if DGNN_FWD_ROWCACHE
+          const float4 ar4 = make_float4(bcast_f32(ar_c.x, rk), bcast_f32(ar_c.y, rk), bcast_f32(ar_c.z, rk),
+                                         bcast_f32(ar_c.w, rk));
+#else
           const float4 ar4 = *(const float4 *)(P.attn_row + (size_t)r * 4);
+#endif
           float4 e4 = make_float4(DGNN_NEG_INIT, DGNN_NEG_INIT, DGNN_NEG_INIT, DGNN_NEG_INIT);
           if (live) {
             const float4 c4 = *(const float4 *)(sc + (size_t)p * 4);
