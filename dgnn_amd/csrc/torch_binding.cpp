@@ -129,6 +129,17 @@ Tensor new_i32(at::IntArrayRef sizes, const Tensor &like) { return at::empty(siz
 Tensor workspace(size_t nbytes, const Tensor &like) {
   return nbytes == 0 ? Tensor() : at::empty({(int64_t)nbytes}, like.options().dtype(at::kByte));
 }
+// Caller-provided outputs (keyword `out`: a sequence, entries may be None): entry i when it is a
+// tensor -- float32, contiguous, on the inputs' device, exactly `sizes` -- else a fresh tensor.
+using OutList = c10::optional<std::vector<OptTensor>>;
+Tensor out_f32(const OutList &out, size_t i, at::IntArrayRef sizes, const Tensor &like, const char *name) {
+  if (!out.has_value() || i >= out->size() || !given((*out)[i])) return new_f32(sizes, like);
+  const Tensor &t = *(*out)[i];
+  f32(t, name);
+  if (t.sizes() != sizes || t.device() != like.device())
+    fail("out: ", name, " must be a float32 tensor of shape ", sizes, " on ", like.device(), ", got ", t.sizes());
+  return t;
+}
 int as_int(int64_t v, const char *what) {
   if (v < 0 || v > INT32_MAX) fail(what, " = ", v, " does not fit the int32 sizes of the C ABI");
   return (int)v;
@@ -154,11 +165,12 @@ GatDims check_gat_fwd(const Tensor &attn_row, const Tensor &attn_col, const Tens
 // -> [out_feat, edge_max, edge_sum, edge_mask]   (fused_gatconv.cpp:11-32)
 std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
                                 const Tensor &col_ind, double negative_slope, const Tensor &in_feat,
-                                double attn_drop, const OptTensor &edge_mask_in) {
+                                double attn_drop, const OptTensor &edge_mask_in, const OutList &outs) {
   const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
   c10::DeviceGuard guard(in_feat.device());
-  Tensor out = new_f32({d.m, d.h, d.f}, in_feat);
-  Tensor edge_max = new_f32({d.m, d.h}, in_feat), edge_sum = new_f32({d.m, d.h}, in_feat);
+  Tensor out = out_f32(outs, 0, {d.m, d.h, d.f}, in_feat, "out_feat");
+  Tensor edge_max = out_f32(outs, 1, {d.m, d.h}, in_feat, "edge_max");
+  Tensor edge_sum = out_f32(outs, 2, {d.m, d.h}, in_feat, "edge_sum");
   Tensor edge_mask;
   if (attn_drop > 0.0) {
     // the reference draws the mask with cuRAND on every call (fused_gatconv_kernel.cu:333-341)
@@ -245,7 +257,8 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
                                  const Tensor &col_ptr, const Tensor &row_ind, const Tensor &permute,
                                  const Tensor &edge_max, const Tensor &edge_sum, const OptTensor &edge_mask,
                                  const Tensor &in_feat, const Tensor &attn_row, const Tensor &attn_col,
-                                 const Tensor &grad, const OptTensor &out_feat, const OptTensor &row_dot) {
+                                 const Tensor &grad, const OptTensor &out_feat, const OptTensor &row_dot,
+                                 const OutList &outs) {
   i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
   i32(permute, "permute");
   f32(edge_max, "edge_max", 2), f32(edge_sum, "edge_sum", 2), f32(in_feat, "in_feat", 3);
@@ -267,8 +280,9 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
   if (given(row_dot)) f32(*row_dot, "row_dot", 2);
   const int have = (given(out_feat) || given(row_dot)) ? 1 : 0;
   c10::DeviceGuard guard(in_feat.device());
-  Tensor grad_feat = new_f32({n, h, f}, in_feat);
-  Tensor grad_attn_row = new_f32({m, h}, in_feat), grad_attn_col = new_f32({n, h}, in_feat);
+  Tensor grad_feat = out_f32(outs, 0, {n, h, f}, in_feat, "grad_feat");
+  Tensor grad_attn_row = out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row");
+  Tensor grad_attn_col = out_f32(outs, 2, {n, h}, in_feat, "grad_attn_col");
   const size_t nb = API(dgnn_gat_backward_workspace_bytes)(m, n, nnz, h, f, have);
   Tensor ws = workspace(nb, in_feat);
   check_rc(API(dgnn_gat_backward)(m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind),
@@ -592,11 +606,12 @@ PYBIND11_MODULE(fused_gatconv, m) {
   options.disable_function_signatures();
   init(m, "Drop-in for the reference's pybind module fused_gatconv (fused_gatconv.cpp:168-174).");
   def(m, "gat_forward", &gat_forward,
-      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask=None",
+      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask=None, out=None",
       "-> [out_feat, edge_max, edge_sum, edge_mask]   (fused_gatconv.cpp:11-32).  The mask is drawn with torch's\n"
-      "generator only when attn_drop > 0 (empty tensor otherwise); edge_mask may be passed explicitly (tests).",
+      "generator only when attn_drop > 0 (empty tensor otherwise); edge_mask may be passed explicitly (tests).\n"
+      "out = (out_feat, edge_max, edge_sum), entries may be None: write into these tensors instead of new ones.",
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
-      arg("attn_drop"), arg("edge_mask") = py::none());
+      arg("attn_drop"), arg("edge_mask") = py::none(), arg("out") = py::none());
   def(m, "gat_forward_tb", &gat_forward_tb,
       "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, tile_scheduler",
       "-> [out_feat, edge_max, edge_sum]   (fused_gatconv.cpp:68-95)", arg("attn_row"), arg("attn_col"),
@@ -611,12 +626,14 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("out_feat"));
   def(m, "gat_backward", &gat_backward,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, "
-      "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None",
+      "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",
       "-> [grad_feat, grad_attn_row, grad_attn_col]   (fused_gatconv.cpp:104-166).  out_feat / row_dot (keywords,\n"
-      "not in the reference signature) remove one whole gather pass from the backward.",
+      "not in the reference signature) remove one whole gather pass from the backward.  out = (grad_feat,\n"
+      "grad_attn_row, grad_attn_col), entries may be None: write into these tensors instead of new ones.",
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("edge_max"), arg("edge_sum"), arg("edge_mask"), arg("in_feat"), arg("attn_row"),
-      arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none());
+      arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
+      arg("out") = py::none());
 }
 
 PYBIND11_MODULE(fused_gmmconv, m) {

@@ -18,13 +18,18 @@ The reference is single-GPU only; this is new d
   the forward on an (n_loc x n_halo) rectangle, the backward on an (n_halo x n_loc) rectangle.
 
 Exchange (``mode``):
-  "halo" (default)  only the rows a rank actually references move: index lists are exchanged
-                    once at set-up, every step is one ``all_to_all_single`` with split sizes per
-                    tensor (direct peer-to-peer over each pair's own xGMI link).  The received
-                    rows arrive ordered by owner rank = globally sorted by node id, so the
-                    receive buffer IS the compact feature table the kernels gather from (column
-                    ids are relabelled to it once at set-up): no scatter pass.  On the
-                    products-shaped R-MAT graph at 8 ranks a rank needs ~35 % of the remote rows.
+  "halo" (default)  only the rows a rank actually references move, and own rows never travel:
+                    index lists are exchanged once at set-up; the block is processed in S chunks
+                    (``DGNN_DIST_CHUNKS``, default 4) of consecutive rows (forward) / columns
+                    (backward), smallest first; chunk s fetches only the remote rows no earlier
+                    chunk fetched, with one ``all_to_all_single`` per tensor (direct peer-to-peer
+                    over each pair's own xGMI link) issued asynchronously on RCCL's stream, so
+                    the exchange of chunk s+1 overlaps the kernels of chunk s.  Received rows
+                    land directly behind the local rows in the table the kernels gather from
+                    (column ids are relabelled to table positions once at set-up): no scatter
+                    pass.  On the products-shaped R-MAT graph at 8 ranks a rank needs ~35 % of
+                    the remote rows; with 4 chunks the first (unhidden) exchange carries ~38 %
+                    of them, with 5 chunks ~24 % (hubs are needed by every chunk).
   "allgather"       every rank receives every row (``dist.all_gather`` on uneven row blocks).
 Set with ``DGNN_DIST_MODE``.  gloo (CPU tests) takes the same code path; CUDA tensors under a
 non-NCCL backend are staged through the host.
@@ -55,38 +60,113 @@ class _NativeOps:
         self._gat = fused_gatconv
         self._fmt = format_conversion
 
-    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat):
-        out, emax, esum, _ = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0)
+    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=None):
+        out, emax, esum, _ = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0,
+                                                   out=out)
         return out, emax, esum
 
     def row_dot(self, grad, out):
         return self._gat.gat_row_dot(grad, out)
 
     def gat_backward(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
-                     in_feat, attn_row, attn_col, grad, row_dot):
+                     in_feat, attn_row, attn_col, grad, row_dot, out=None):
         return self._gat.gat_backward(slope, 0.0, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max,
-                                      edge_sum, None, in_feat, attn_row, attn_col, grad, row_dot=row_dot)
+                                      edge_sum, None, in_feat, attn_row, attn_col, grad, row_dot=row_dot, out=out)
 
     def transpose(self, ptr, ind, n_cols):
         """(ptr, ind) = CSR of an (r x n_cols) matrix -> (ptr_T [n_cols+1], ind_T, perm)."""
         return self._fmt.csr2csc_int(ptr, ind, n_cols=n_cols)
 
 
+def chunk_fractions(chunks):
+    """Shares of a block's edges given to its chunks: 1/2^(S-1), 1/2^(S-1), 1/2^(S-2), ..., 1/2.
+    The FIRST exchange cannot be hidden behind compute, so the first chunk is the smallest; on a
+    power-law graph it still pulls in the hubs (~1/4 of the halo for 1/16 of the edges)."""
+    if chunks <= 1:
+        return [1.0]
+    return [0.5 ** (chunks - 1)] + [0.5 ** (chunks - i) for i in range(1, chunks)]
+
+
 class _Halo:
-    """Who needs which of my rows, and which rows I need, for one direction of the exchange."""
+    """Who needs which of my rows, and which rows I need, for ONE chunk of one direction."""
 
     def __init__(self, owner, needed_ids):
-        """needed_ids: sorted unique GLOBAL node ids (int64) this rank references."""
+        """needed_ids: sorted unique GLOBAL ids (int64) of REMOTE nodes this chunk adds."""
         self.n_needed = needed_ids.numel()
         b = torch.tensor(owner.bounds, dtype=torch.int64, device=needed_ids.device)
         cut = torch.searchsorted(needed_ids, b)                      # [world+1]
         self.recv_counts = [int(c) for c in (cut[1:] - cut[:-1]).cpu()]
-        send_counts = owner._a2a_counts(self.recv_counts)
-        self.send_counts = send_counts
-        wanted = torch.empty(sum(send_counts), dtype=torch.int64, device=needed_ids.device)
-        owner._a2a(wanted, needed_ids, send_counts, self.recv_counts)   # ids the peers want from me
+        self.send_counts = owner._a2a_counts(self.recv_counts)
+        wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=needed_ids.device)
+        owner._a2a(wanted, needed_ids, self.send_counts, self.recv_counts)   # ids the peers want from me
         self.send_idx = (wanted - owner.lo).contiguous()                # local row indices, by peer
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < owner.n_loc)
+
+
+class _Side:
+    """One direction of the exchange for a rank's block, cut into chunks.
+
+    The block is a compressed matrix whose OUTER index is local (forward: the rank's CSR rows;
+    backward: its CSC columns) and whose INNER index is global (sources / destinations).  Outer
+    entries are independent in the kernels, so the block is processed as S chunks of consecutive
+    outer entries, smallest first (``chunk_fractions``).  Chunk s needs the remote inner nodes no
+    earlier chunk has fetched; they are appended to a table laid out as
+        [ local rows (n_loc) | new rows of chunk 0 | new rows of chunk 1 | ... ]
+    (inner ids are relabelled to table positions once), so chunk s reads only the prefix that has
+    arrived and the exchange of chunk s+1 runs while chunk s computes.  Own rows never travel.
+    """
+
+    def __init__(self, owner, ptr, ind, chunks):
+        dev = ind.device
+        n, lo, hi, n_loc = owner.n, owner.lo, owner.hi, owner.n_loc
+        ptr = ptr.to(torch.int64)
+        ind = ind.to(torch.int64)
+        nnz = int(ptr[-1]) if ptr.numel() else 0
+        acc, cuts = 0.0, [0]
+        for fr in chunk_fractions(chunks)[:-1]:
+            acc += fr
+            cuts.append(int(torch.searchsorted(ptr, torch.tensor([int(acc * nnz)], device=dev))[0]))
+        cuts.append(n_loc)
+        cuts = [min(max(c, 0), n_loc) for c in cuts]
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+        self.cuts = cuts
+        pos = torch.full((n,), -1, dtype=torch.int64, device=dev)     # global id -> table position
+        pos[lo:hi] = torch.arange(n_loc, device=dev)
+        self.halos, self.offs = [], []
+        off = n_loc
+        for s in range(len(cuts) - 1):
+            c = ind[int(ptr[cuts[s]]):int(ptr[cuts[s + 1]])]
+            u = torch.unique(c[(c < lo) | (c >= hi)])                    # sorted distinct remote ids
+            new = u[pos[u] < 0]
+            pos[new] = off + torch.arange(new.numel(), device=dev)
+            self.halos.append(_Halo(owner, new))
+            self.offs.append(off)
+            off += new.numel()
+        self.n_table = off
+        rel = pos[ind]
+        assert rel.numel() == 0 or int(rel.min()) >= 0
+        self.blocks = []                                                  # (outer range, ptr_s, ind_s, visible table rows)
+        for s in range(len(cuts) - 1):
+            a, b = cuts[s], cuts[s + 1]
+            e0, e1 = int(ptr[a]), int(ptr[b])
+            self.blocks.append((a, b, (ptr[a:b + 1] - ptr[a]).to(torch.int32).contiguous(),
+                                rel[e0:e1].to(torch.int32).contiguous(), self.offs[s] + self.halos[s].n_needed))
+        # return path (additive results of remote table rows go back to their owners in ONE
+        # all-to-all): table rows regrouped by owner, chunks ascending inside an owner
+        world = owner.world
+        take, give = [], []
+        self.ret_send_counts, self.ret_recv_counts = [0] * world, [0] * world
+        for q in range(world):
+            for s, h in enumerate(self.halos):
+                r0 = sum(h.recv_counts[:q])
+                take.append(torch.arange(self.offs[s] + r0, self.offs[s] + r0 + h.recv_counts[q], device=dev))
+                s0 = sum(h.send_counts[:q])
+                give.append(h.send_idx[s0:s0 + h.send_counts[q]])
+                self.ret_send_counts[q] += h.recv_counts[q]
+                self.ret_recv_counts[q] += h.send_counts[q]
+        self.ret_take = torch.cat(take) if take else torch.empty(0, dtype=torch.int64, device=dev)
+        self.ret_give = torch.cat(give) if give else torch.empty(0, dtype=torch.int64, device=dev)
 
 
 class PartitionedGAT:
@@ -95,10 +175,11 @@ class PartitionedGAT:
     ``graph`` holds the FULL index arrays (row_ptr, col_ind, col_ptr, row_ind as int32 tensors on
     ``device``); only this rank's blocks are kept afterwards.  ``ops`` is the compute backend
     (default: the HIP kernels); tests inject a CPU stand-in to exercise the partition and the
-    collectives without a GPU.
+    collectives without a GPU.  ``chunks`` (halo mode; default DGNN_DIST_CHUNKS or 4 when
+    world > 1) pipelines the exchange against the compute, see ``_Side``.
     """
 
-    def __init__(self, graph, world, rank, device, ops=None, group=None, mode=None):
+    def __init__(self, graph, world, rank, device, ops=None, group=None, mode=None, chunks=None):
         self.world, self.rank, self.device, self.group = world, rank, device, group
         self.ops = ops if ops is not None else _NativeOps()
         self.mode = mode or os.environ.get("DGNN_DIST_MODE", "halo")
@@ -107,6 +188,9 @@ class PartitionedGAT:
         self._solo = world == 1 and os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") != "1"
         if self.mode not in ("halo", "allgather"):
             raise ValueError(f"unknown exchange mode {self.mode!r}")
+        if chunks is None:
+            chunks = int(os.environ.get("DGNN_DIST_CHUNKS", "4" if world > 1 else "1"))
+        self.chunks = max(1, int(chunks)) if self.mode == "halo" else 1
         row_ptr, col_ind = graph["row_ptr"], graph["col_ind"]
         col_ptr, row_ind = graph["col_ptr"], graph["row_ind"]
         self.n = row_ptr.numel() - 1
@@ -115,31 +199,35 @@ class PartitionedGAT:
         self.lo, self.hi, self.n_loc = lo, hi, hi - lo
         # forward block  A[lo:hi, :]  (CSR)
         e0, e1 = int(row_ptr[lo]), int(row_ptr[hi])
-        self.f_row_ptr = (row_ptr[lo:hi + 1] - row_ptr[lo]).to(torch.int32).contiguous()
+        f_ptr = row_ptr[lo:hi + 1] - row_ptr[lo]
         f_col = col_ind[e0:e1].contiguous()
         # backward block  A[:, lo:hi]  (CSC)
         c0, c1 = int(col_ptr[lo]), int(col_ptr[hi])
-        self.b_col_ptr = (col_ptr[lo:hi + 1] - col_ptr[lo]).to(torch.int32).contiguous()
+        b_ptr = col_ptr[lo:hi + 1] - col_ptr[lo]
         b_row = row_ind[c0:c1].contiguous()
         self.nnz_fwd, self.nnz_bwd = e1 - e0, c1 - c0
         if self.mode == "halo":
-            uf = torch.unique(f_col.long())                           # sorted distinct sources
-            self.f_col_ind = torch.searchsorted(uf, f_col.long()).to(torch.int32).contiguous()
-            self.f_halo = _Halo(self, uf)
-            ub = torch.unique(b_row.long())                           # sorted distinct destinations
-            self.b_row_ind = torch.searchsorted(ub, b_row.long()).to(torch.int32).contiguous()
-            self.b_halo = _Halo(self, ub)
-            n_rows_b = ub.numel()
+            self.f_side = _Side(self, f_ptr, f_col, self.chunks)
+            self.b_side = _Side(self, b_ptr, b_row, self.chunks)
+            b_blocks = self.b_side.blocks
         else:
-            self.f_col_ind, self.b_row_ind, n_rows_b = f_col, b_row, self.n
-        # the backward block's own CSR ordering (for the per-row sum of the edge gradients)
-        b_row_ptr, b_col_ind, perm2 = self.ops.transpose(self.b_col_ptr, self.b_row_ind, n_rows_b)
-        self.b_row_ptr, self.b_col_ind = b_row_ptr, b_col_ind
-        # perm2[j] = CSC position of the block's CSR entry j; the kernels want the inverse
-        inv = torch.empty_like(perm2)
-        inv[perm2.long()] = torch.arange(perm2.numel(), dtype=perm2.dtype, device=perm2.device)
-        self.b_permute = inv
+            self.f_row_ptr = f_ptr.to(torch.int32).contiguous()
+            self.f_col_ind = f_col
+            b_blocks = [(0, self.n_loc, b_ptr.to(torch.int32).contiguous(), b_row, self.n)]
+        # every backward block's own CSR ordering (for the per-row sum of the edge gradients)
+        self.b_blocks = []
+        for a, b, cptr, rind, n_rows in b_blocks:
+            rptr, cind, perm2 = self.ops.transpose(cptr, rind, n_rows)
+            # perm2[j] = CSC position of the block's CSR entry j; the kernels want the inverse
+            inv = torch.empty_like(perm2)
+            inv[perm2.long()] = torch.arange(perm2.numel(), dtype=perm2.dtype, device=perm2.device)
+            self.b_blocks.append((a, b, cptr, rind, n_rows, rptr, cind, inv))
+        # dimensions of the largest chunk (bench.py prices the kernels of the LAST launch)
+        self.last_fwd = ((self.f_side.blocks[-1][1] - self.f_side.blocks[-1][0], self.f_side.blocks[-1][3].numel())
+                         if self.mode == "halo" else (self.n_loc, self.nnz_fwd))
+        self.last_bwd = (self.b_blocks[-1][1] - self.b_blocks[-1][0], self.b_blocks[-1][3].numel())
         self._ctx = None
+        self._tables = {}
 
     # ------------------------------------------------------------------ collectives
     def _nccl(self):
@@ -154,37 +242,56 @@ class PartitionedGAT:
         dist.all_to_all_single(out, inp, group=self.group)
         return [int(c) for c in out.cpu()]
 
-    def _a2a(self, out, inp, out_splits, in_splits):
-        """out (rows grouped by source rank) <- inp (rows grouped by destination rank)."""
+    def _a2a(self, out, inp, out_splits, in_splits, async_op=False):
+        """out (rows grouped by source rank) <- inp (rows grouped by destination rank).  With
+        ``async_op`` (RCCL only) the exchange runs on the communicator's stream and the returned
+        handle's wait() orders the CURRENT stream after it; the handle keeps ``inp`` alive."""
         if self._solo:
             out.copy_(inp)
-            return out
+            return None
         if self._nccl() or not inp.is_cuda:
-            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
-        else:                                   # e.g. gloo with device tensors: stage through the host
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.contiguous().cpu(), out_splits, in_splits, group=self.group)
-            out.copy_(o)
-        return out
+            inp = inp.contiguous()
+            work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group,
+                                          async_op=async_op and self._nccl())
+            return (work, inp) if work is not None else None
+        # e.g. gloo with device tensors: stage through the host
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.contiguous().cpu(), out_splits, in_splits, group=self.group)
+        out.copy_(o)
+        return None
 
-    def _fetch(self, halo, local):
-        """Rows of every peer that this rank references (plus its own), in node-id order."""
-        send = local.index_select(0, halo.send_idx)
-        table = torch.empty((halo.n_needed,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        return self._a2a(table, send, halo.recv_counts, halo.send_counts)
+    @staticmethod
+    def _wait(handles):
+        for h in handles:
+            if h is not None:
+                h[0].wait()
 
-    def _return_rows(self, halo, partial):
-        """Inverse of _fetch for additive results: partial [n_needed,...] rows go back to their
-        owners and are summed there in a fixed (peer) order."""
-        back = torch.empty((halo.send_idx.numel(),) + tuple(partial.shape[1:]), dtype=partial.dtype,
-                           device=partial.device)
-        self._a2a(back, partial, halo.send_counts, halo.recv_counts)
-        acc = torch.zeros((self.n_loc,) + tuple(partial.shape[1:]), dtype=partial.dtype, device=partial.device)
+    def _start_fetch(self, side, tables, locals_):
+        """Start every chunk's exchange, in chunk order: for each chunk the rows the peers need of
+        each tensor in ``locals_`` are packed and sent, and the rows this rank needs land directly
+        in their place in ``tables`` (no scatter pass).  -> per-chunk handle lists."""
+        handles = []
+        for s, h in enumerate(side.halos):
+            hs = []
+            for table, local in zip(tables, locals_):
+                send = local.index_select(0, h.send_idx)
+                hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
+                                    h.send_counts, async_op=True))
+            handles.append(hs)
+        return handles
+
+    def _return_rows(self, side, partial):
+        """Inverse of the fetches for additive results: the remote rows of ``partial``
+        [n_table, ...] go back to their owners (one all-to-all) and are added there in a fixed
+        (peer, chunk) order; -> this rank's [n_loc, ...] rows."""
+        acc = partial[:self.n_loc].clone()
+        give = side.ret_give
+        back = torch.empty((give.numel(),) + tuple(partial.shape[1:]), dtype=partial.dtype, device=partial.device)
+        self._a2a(back, partial.index_select(0, side.ret_take), side.ret_recv_counts, side.ret_send_counts)
         off = 0
-        for cnt in halo.send_counts:              # ids are distinct inside one peer's list
+        for cnt in side.ret_recv_counts:          # ids are distinct inside one peer's list
             if cnt:
-                idx = halo.send_idx[off:off + cnt]
-                acc[idx] += back[off:off + cnt]
+                acc[give[off:off + cnt]] += back[off:off + cnt]
             off += cnt
         return acc
 
@@ -204,19 +311,53 @@ class PartitionedGAT:
                 dist.broadcast(views[q], src=q, group=self.group)
         return full
 
-    def _rows_for_forward(self, local):
-        return self._fetch(self.f_halo, local) if self.mode == "halo" else self._all_gather_rows(local)
+    def _table(self, side, local, name):
+        """The gather table of ``side`` for tensor ``name``: [n_table, ...] with the local rows in
+        front.  Tables are kept between steps; when ``local`` IS the table's local part (the
+        caller filled ``input_buffer``) no copy is made."""
+        key = (id(side), name, tuple(local.shape[1:]), local.dtype)
+        t = self._tables.get(key)
+        if t is None:
+            t = torch.empty((side.n_table,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            self._tables[key] = t
+        if local.data_ptr() != t.data_ptr():
+            t[:self.n_loc].copy_(local)
+        return t
 
-    def _rows_for_backward(self, local):
-        return self._fetch(self.b_halo, local) if self.mode == "halo" else self._all_gather_rows(local)
+    def input_buffer(self, which, tail_shape, dtype=torch.float32):
+        """[n_loc, *tail_shape] view of the local part of a gather table (halo mode): produce the
+        layer input (``which`` = "forward": in_feat) or the output gradient ("backward": grad_out)
+        directly into it and pass it to forward() / backward(): the step then starts without
+        copying the local rows.  The table is overwritten by the next step of this runner (one
+        runner per layer)."""
+        if self.mode != "halo":
+            return torch.empty((self.n_loc,) + tuple(tail_shape), dtype=dtype, device=self.device)
+        side, name = (self.f_side, "in_feat") if which == "forward" else (self.b_side, "grad")
+        key = (id(side), name, tuple(tail_shape), dtype)
+        if key not in self._tables:
+            self._tables[key] = torch.empty((side.n_table,) + tuple(tail_shape), dtype=dtype, device=self.device)
+        return self._tables[key][:self.n_loc]
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, in_feat_loc, attn_row_loc, attn_col_loc, slope):
         """Local rows of GATConvFuse(...): [n_loc,H,F]."""
-        in_tab = self._rows_for_forward(in_feat_loc.contiguous())
-        ac_tab = self._rows_for_forward(attn_col_loc.contiguous())
-        out, emax, esum = self.ops.gat_forward(attn_row_loc.contiguous(), ac_tab, self.f_row_ptr,
-                                               self.f_col_ind, slope, in_tab)
+        in_feat_loc, attn_row_loc = in_feat_loc.contiguous(), attn_row_loc.contiguous()
+        attn_col_loc = attn_col_loc.contiguous()
+        if self.mode == "halo":
+            side = self.f_side
+            in_tab, ac_tab = self._table(side, in_feat_loc, "in_feat"), self._table(side, attn_col_loc, "attn_col")
+            handles = self._start_fetch(side, (ac_tab, in_tab), (attn_col_loc, in_feat_loc))
+            h = attn_row_loc.size(1)
+            out = torch.empty((self.n_loc,) + tuple(in_feat_loc.shape[1:]), dtype=in_feat_loc.dtype, device=in_feat_loc.device)
+            emax = torch.empty((self.n_loc, h), dtype=in_feat_loc.dtype, device=in_feat_loc.device)
+            esum = torch.empty_like(emax)
+            for s, (a, b, ptr, ind, n_vis) in enumerate(side.blocks):   # every chunk writes its own rows
+                self._wait(handles[s])
+                self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
+                                     out=(out[a:b], emax[a:b], esum[a:b]))
+        else:
+            in_tab, ac_tab = self._all_gather_rows(in_feat_loc), self._all_gather_rows(attn_col_loc)
+            out, emax, esum = self.ops.gat_forward(attn_row_loc, ac_tab, self.f_row_ptr, self.f_col_ind, slope, in_tab)
         self._ctx = (in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope)
         return out
 
@@ -224,20 +365,33 @@ class PartitionedGAT:
         """-> (grad_feat_loc [n_loc,H,F], grad_attn_row_loc [n_loc,H], grad_attn_col_loc [n_loc,H])."""
         in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope = self._ctx
         grad_out_loc = grad_out_loc.contiguous()
-        grad_tab = self._rows_for_backward(grad_out_loc)
         S_loc = self.ops.row_dot(grad_out_loc, out)
         stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=1).contiguous()   # [n_loc,4,H]
-        stat = self._rows_for_backward(stat_loc).permute(1, 0, 2).contiguous()          # [4,rows,H]
-        gf, gr_partial, gc = self.ops.gat_backward(
-            slope, self.b_row_ptr, self.b_col_ind, self.b_col_ptr, self.b_row_ind, self.b_permute,
-            stat[1], stat[2], in_feat_loc.contiguous(), stat[0], attn_col_loc.contiguous(), grad_tab,
-            stat[3])
         if self.mode == "halo":
-            gr = self._return_rows(self.b_halo, gr_partial)
+            side = self.b_side
+            grad_tab, stat_tab = self._table(side, grad_out_loc, "grad"), self._table(side, stat_loc, "stat")
+            handles = self._start_fetch(side, (stat_tab, grad_tab), (stat_loc, grad_out_loc))
+        else:
+            grad_tab, stat_tab = self._all_gather_rows(grad_out_loc), self._all_gather_rows(stat_loc)
+            handles = [[]]
+        gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(2)), dtype=stat_tab.dtype, device=stat_tab.device)
+        gf = torch.empty_like(in_feat_loc)
+        gc = torch.empty_like(attn_col_loc)
+        for s, (a, b, cptr, rind, n_vis, rptr, cind, perm) in enumerate(self.b_blocks):
+            self._wait(handles[s])
+            stat = stat_tab[:n_vis].permute(1, 0, 2).contiguous()                         # [4,rows,H]
+            # every chunk writes its own columns of grad_feat / grad_attn_col; its grad_attn_row
+            # is a partial sum over the table rows it can see
+            _, gr_part, _ = self.ops.gat_backward(slope, rptr, cind, cptr, rind, perm, stat[1], stat[2],
+                                                  in_feat_loc[a:b], stat[0], attn_col_loc[a:b], grad_tab[:n_vis],
+                                                  stat[3], out=(gf[a:b], None, gc[a:b]))
+            gr_tab[:n_vis] += gr_part
+        if self.mode == "halo":
+            gr = self._return_rows(self.b_side, gr_tab)
         else:
             if not self._solo:
-                dist.all_reduce(gr_partial, group=self.group)
-            gr = gr_partial[self.lo:self.hi].contiguous()
+                dist.all_reduce(gr_tab, group=self.group)
+            gr = gr_tab[self.lo:self.hi].contiguous()
         return gf, gr, gc
 
     def step(self, in_feat, attn_row, attn_col, grad_out, slope):

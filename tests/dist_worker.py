@@ -34,10 +34,17 @@ class OracleOps:
     def _t(a, dtype=None):
         return torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
 
-    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat):
-        out, emax, esum = self.o.gat_forward(attn_row.numpy(), attn_col.numpy(), row_ptr.numpy(),
-                                             col_ind.numpy(), slope, in_feat.numpy(), 0.0)
-        return self._t(out), self._t(emax), self._t(esum)
+    @staticmethod
+    def _emit(results, out):
+        """Honour the `out=` convention of the native module: write into the given tensors."""
+        if out is not None:
+            results = tuple(r if o is None else o.copy_(r) for r, o in zip(results, out))
+        return results
+
+    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=None):
+        res = self.o.gat_forward(attn_row.numpy(), attn_col.numpy(), row_ptr.numpy(),
+                                 col_ind.numpy(), slope, in_feat.numpy(), 0.0)
+        return self._emit(tuple(self._t(r) for r in res), out)
 
     def row_dot(self, grad, out):
         return (grad.double() * out.double()).sum(-1).float()
@@ -47,7 +54,7 @@ class OracleOps:
         return self._t(cp), self._t(ri), self._t(pm)
 
     def gat_backward(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
-                     in_feat, attn_row, attn_col, grad, row_dot):
+                     in_feat, attn_row, attn_col, grad, row_dot, out=None):
         """Same dataflow as the HIP backward: one pass over the CSC, d written to CSR order through
         `permute`, row sums over the block's own row_ptr."""
         cp, ri, pm = col_ptr.numpy().astype(np.int64), row_ind.numpy().astype(np.int64), permute.numpy().astype(np.int64)
@@ -74,7 +81,7 @@ class OracleOps:
         assert np.array_equal(rows_csr[pm], ri), "permute / row_ptr of the backward block disagree"
         gr = np.zeros((m, ar.shape[1]))
         np.add.at(gr, rows_csr, dE)
-        return self._t(gf, np.float32), self._t(gr, np.float32), self._t(gc, np.float32)
+        return self._emit((self._t(gf, np.float32), self._t(gr, np.float32), self._t(gc, np.float32)), out)
 
 
 def run(rank, world, mode, port, out_dir, graph_spec, h, f):
@@ -95,7 +102,11 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     runner = PartitionedGAT(G, world, rank, device, ops=ops)
     lo, hi = runner.lo, runner.hi
     t = lambda a: torch.from_numpy(a).to(device)
-    out = runner.forward(t(in_feat[lo:hi]), t(attn_row[lo:hi]), t(attn_col[lo:hi]), 0.2)
+    # the layer input is produced straight into the runner's gather table (no copy of local rows);
+    # the output gradient goes the ordinary way (copied in)
+    x_loc = runner.input_buffer("forward", (h, f))
+    x_loc.copy_(t(in_feat[lo:hi]))
+    out = runner.forward(x_loc, t(attn_row[lo:hi]), t(attn_col[lo:hi]), 0.2)
     gf, gr, gc = runner.backward(t(grad[lo:hi]))
     if device.type == "cuda":
         torch.cuda.synchronize()

@@ -27,9 +27,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(world, mode, spec, h, f, exchange="halo"):
+def run_world(world, mode, spec, h, f, exchange="halo", chunks=None):
     port = free_port()
     env = dict(os.environ, DGNN_DIST_MODE=exchange)
+    if chunks is not None:
+        env["DGNN_DIST_CHUNKS"] = str(chunks)
     with tempfile.TemporaryDirectory() as out_dir:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world),
                                    mode, str(port), out_dir, ",".join(map(str, spec)), str(h), str(f)], env=env)
@@ -73,6 +75,29 @@ def check(parts, spec, h, f):
 def test_partitioned_gat_cpu_gloo(world, exchange):
     spec, h, f = (10, 700, 6000, 5), 2, 8
     check(run_world(world, "cpu", spec, h, f, exchange), spec, h, f)
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2), (2, 6)])
+def test_partitioned_gat_cpu_gloo_chunked_pipeline(world, chunks):
+    """The chunked exchange (default 4 chunks above) with 1, 2 and 6 chunks: same result."""
+    spec, h, f = (10, 700, 6000, 5), 2, 8
+    check(run_world(world, "cpu", spec, h, f, "halo", chunks), spec, h, f)
+
+
+def test_chunk_fractions_and_incremental_tables():
+    import torch
+    from dgnn_amd.dist import PartitionedGAT, chunk_fractions
+    for c in (1, 2, 4, 7):
+        fr = chunk_fractions(c)
+        assert len(fr) == c and abs(sum(fr) - 1.0) < 1e-12 and fr == sorted(fr)
+    # one rank, no collectives: every chunk's table prefix is just the local rows
+    g = rmat_graph(10, 700, 6000, 5)
+    G = {k: torch.from_numpy(g[k]) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
+    import dist_worker
+    r = PartitionedGAT(G, 1, 0, torch.device("cpu"), ops=dist_worker.OracleOps(), chunks=3)
+    assert [b[1] - b[0] for b in r.f_side.blocks] and r.f_side.blocks[-1][1] == g["n"]
+    assert all(b[4] == g["n"] for b in r.f_side.blocks) and r.f_side.n_table == g["n"]
+    assert sum(b[3].numel() for b in r.f_side.blocks) == g["nnz"] == sum(b[3].numel() for b in r.b_blocks)
 
 
 @pytest.mark.gpu

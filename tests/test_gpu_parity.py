@@ -117,6 +117,34 @@ def test_gat_every_group_size(nat, name, fwd_l, bwd_l, monkeypatch):
     assert_close(host(gc), gc64, "grad_attn_col", mass=m_gc)
 
 
+def test_gat_caller_provided_outputs(nat):
+    """out=(...) of gat_forward / gat_backward (row slices of larger tensors, as the chunked
+    multi-GPU runner passes them): same bits as the allocating call, written in place; wrong
+    shapes are refused."""
+    import dgnn_amd
+    g = GRAPHS["rmat4k"]
+    h, f = 4, 64
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=5)
+    G = gdev(g)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    ref = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, 0.0)
+    big = torch.full((g["n"] + 7, h, f), 7.0, device=DEV)
+    emax, esum = torch.empty((g["n"], h), device=DEV), torch.empty((g["n"], h), device=DEV)
+    got = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, 0.0, out=(big[3:3 + g["n"]], emax, esum))
+    assert got[0].data_ptr() == big[3:].data_ptr() and got[1].data_ptr() == emax.data_ptr()
+    assert torch.equal(big[3:3 + g["n"]], ref[0]) and torch.equal(emax, ref[1]) and torch.equal(esum, ref[2])
+    assert float(big[:3].min()) == 7.0 and float(big[3 + g["n"]:].max()) == 7.0      # nothing outside the view
+    bref = nat["gat"].gat_backward(0.2, 0.0, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                   ref[1], ref[2], None, x, ar, ac, go, out_feat=ref[0])
+    gf, gc = torch.empty_like(x), torch.empty_like(ac)
+    bgot = nat["gat"].gat_backward(0.2, 0.0, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                   ref[1], ref[2], None, x, ar, ac, go, out_feat=ref[0], out=(gf, None, gc))
+    assert bgot[0].data_ptr() == gf.data_ptr() and bgot[2].data_ptr() == gc.data_ptr()
+    assert all(torch.equal(a, b) for a, b in zip(bgot, bref))
+    with pytest.raises(dgnn_amd.DgnnError):
+        nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, 0.0, out=(big, None, None))
+
+
 @pytest.mark.parametrize("name", ["tiny", "powerlaw256", "rmat4k"])
 def test_gat_inference_and_tiles(nat, name):
     g = GRAPHS[name]

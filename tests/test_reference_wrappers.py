@@ -43,13 +43,13 @@ def _bound(native_mod_name, fn_name, impl):
 
 @pytest.fixture()
 def ref_ops(monkeypatch):
-    def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask):
+    def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask, out):
         out, emax, esum = oracle.gat_forward(N(attn_row), N(attn_col), N(row_ptr), N(col_ind), negative_slope,
                                              N(in_feat), attn_drop, None)
         return [T(out), T(emax), T(esum), torch.empty((0, attn_row.size(1)))]
 
     def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
-                     edge_mask, in_feat, attn_row, attn_col, grad, out_feat, row_dot):
+                     edge_mask, in_feat, attn_row, attn_col, grad, out_feat, row_dot, out):
         gf, gr, gc = oracle.gat_backward(negative_slope, attn_drop, N(row_ptr), N(col_ind), N(col_ptr), N(row_ind),
                                          N(permute), N(edge_max), N(edge_sum), None, N(in_feat), N(attn_row),
                                          N(attn_col), N(grad))
