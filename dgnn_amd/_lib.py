@@ -33,6 +33,7 @@ SIGNATURES = {
     "dgnn_gat_row_dot": (_i, [_i, _i, _i] + [_vp] * 3 + [_vp]),
     "dgnn_gat_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 17 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward_packed": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 13 + [_vp, _sz, _vp]),
     "dgnn_spmm_csr_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_spmm_csr": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_mhsddmm": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp]),

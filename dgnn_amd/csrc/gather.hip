@@ -318,24 +318,30 @@ size_t dgnn_gat_backward_workspace_bytes(int m, int n, int nnz, int h, int f, in
   return bwd_layout(m, n, nnz, h, f, !have_row_term).total;
 }
 
-int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
-                      const int *row_ptr, const int *col_ind, const int *col_ptr,
-                      const int *row_ind, const int *permute, const float *edge_max,
-                      const float *edge_sum, const float *edge_mask, const float *in_feat,
-                      const float *attn_row, const float *attn_col, const float *grad,
-                      const float *out_feat, const float *row_dot, float *grad_feat,
-                      float *grad_attn_row, float *grad_attn_col, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+}  // extern "C"
+
+// Body of dgnn_gat_backward / dgnn_gat_backward_packed.  `packed` != NULL: the per-row inputs
+// arrive as the float4 table the gather kernel reads ({attn_row, edge_max, edge_sum, row_dot} per
+// (row, head)), so the packing pass is skipped; only the fast path takes it.
+static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
+                             const int *row_ptr, const int *col_ind, const int *col_ptr,
+                             const int *row_ind, const int *permute, const float *edge_max,
+                             const float *edge_sum, const float *edge_mask, const float *in_feat,
+                             const float *attn_row, const float *attn_col, const float *grad,
+                             const float *out_feat, const float *row_dot, const float4 *packed,
+                             float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                             void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (n < 0) return DGNN_ERR_BAD_ARG;
   if (!row_ptr || !col_ptr) return DGNN_ERR_BAD_ARG;
-  if (m > 0 && (!edge_max || !edge_sum || !attn_row || !grad || !grad_attn_row)) return DGNN_ERR_BAD_ARG;
+  if (m > 0 && !packed && (!edge_max || !edge_sum || !attn_row)) return DGNN_ERR_BAD_ARG;
+  if (m > 0 && (!grad || !grad_attn_row)) return DGNN_ERR_BAD_ARG;
   if (n > 0 && (!in_feat || !attn_col || !grad_feat || !grad_attn_col)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && (!col_ind || !row_ind || !permute)) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
   if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
-  const bool have_row_term = (out_feat != nullptr) || (row_dot != nullptr) || m == 0;
+  const bool have_row_term = (out_feat != nullptr) || (row_dot != nullptr) || (packed != nullptr) || m == 0;
   BwdLayout w = bwd_layout(m, n, nnz, h, f, !have_row_term);
   if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -358,6 +364,7 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
   bool fast = w.fast && (h != 4 || aligned16(attn_col)) &&
               (vec == 1 || (aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
                             (out == nullptr || aligned16(out))));
+  if (packed != nullptr && !(fast && aligned16(packed))) return DGNN_ERR_UNSUPPORTED;
   if (fast) {
     BwdParams P = {};
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
@@ -369,11 +376,11 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     P.attn_row = attn_row; P.attn_col = attn_col; P.edge_max = edge_max; P.edge_sum = edge_sum;
     P.edge_mask = mask; P.in_feat = in_feat; P.grad = grad; P.out_feat = out;
     P.S_in = row_dot;
-    P.rowstat = (float4 *)(ws + w.off_stat);
+    P.rowstat = packed ? const_cast<float4 *>(packed) : (float4 *)(ws + w.off_stat);
     P.dE = dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
     P.task_col0 = (int *)(ws + w.off_cols);
     P.slots = (float *)(ws + w.off_slots);
-    if (m > 0) {
+    if (m > 0 && !packed) {
       if (vec == 4)
         hipLaunchKernelGGL(k_bwd_rowstat<4>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
       else
@@ -440,6 +447,37 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
     DGNN_LAUNCH_CHECK();
   }
   return DGNN_OK;
+}
+
+extern "C" {
+
+int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
+                      const int *row_ptr, const int *col_ind, const int *col_ptr,
+                      const int *row_ind, const int *permute, const float *edge_max,
+                      const float *edge_sum, const float *edge_mask, const float *in_feat,
+                      const float *attn_row, const float *attn_col, const float *grad,
+                      const float *out_feat, const float *row_dot, float *grad_feat,
+                      float *grad_attn_row, float *grad_attn_col, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
+                           permute, edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad, out_feat,
+                           row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
+                           workspace_bytes, stream);
+}
+
+int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
+                             const int *row_ptr, const int *col_ind, const int *col_ptr,
+                             const int *row_ind, const int *permute, const float *row_stat,
+                             const float *edge_mask, const float *in_feat, const float *attn_col,
+                             const float *grad, float *grad_feat, float *grad_attn_row,
+                             float *grad_attn_col, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+  if (m > 0 && !row_stat) return DGNN_ERR_BAD_ARG;
+  if (m == 0) row_stat = nullptr;
+  return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
+                           permute, nullptr, nullptr, edge_mask, in_feat, nullptr, attn_col, grad, nullptr,
+                           nullptr, (const float4 *)row_stat, grad_feat, grad_attn_row, grad_attn_col,
+                           workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------- GE-SpMM / GMM

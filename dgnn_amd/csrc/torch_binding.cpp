@@ -294,6 +294,44 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
   return {grad_feat, grad_attn_row, grad_attn_col};
 }
 
+// gat_backward with the per-row inputs packed: row_stat [m,h,4] = {attn_row, edge_max, edge_sum,
+// row_dot} (include/dgnn_hip.h, dgnn_gat_backward_packed).  -> [grad_feat, grad_attn_row,
+// grad_attn_col], or None where the packed entry point does not apply (caller unpacks).
+py::object gat_backward_packed(double negative_slope, double attn_drop, const Tensor &row_ptr, const Tensor &col_ind,
+                               const Tensor &col_ptr, const Tensor &row_ind, const Tensor &permute,
+                               const Tensor &row_stat, const OptTensor &edge_mask, const Tensor &in_feat,
+                               const Tensor &attn_col, const Tensor &grad, const OutList &outs) {
+  i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
+  i32(permute, "permute");
+  f32(row_stat, "row_stat", 3), f32(in_feat, "in_feat", 3), f32(attn_col, "attn_col", 2), f32(grad, "grad", 3);
+  const int m = as_int(row_ptr.size(0) - 1, "rows"), nnz = as_int(col_ind.size(0), "nnz");
+  const int n = as_int(col_ptr.size(0) - 1, "columns");
+  const int h = as_int(in_feat.size(1), "heads"), f = as_int(in_feat.size(2), "features");
+  if (in_feat.size(0) != n || attn_col.size(0) != n || attn_col.size(1) != h)
+    fail("gat_backward_packed: in_feat/attn_col rows must equal len(col_ptr)-1");
+  if (row_stat.size(0) != m || row_stat.size(1) != h || row_stat.size(2) != 4)
+    fail("gat_backward_packed: row_stat must be [len(row_ptr)-1, h, 4]");
+  if (grad.size(0) != m || grad.size(1) != h || grad.size(2) != f) fail("gat_backward_packed: grad must be [m,h,f]");
+  if (row_ind.size(0) != nnz || permute.size(0) != nnz) fail("gat_backward_packed: row_ind / permute must hold nnz entries");
+  if (attn_drop > 0.0) {
+    if (!given(edge_mask)) fail("gat_backward_packed: edge_mask is required when attn_drop > 0");
+    f32(*edge_mask, "edge_mask", 2);
+  }
+  c10::DeviceGuard guard(in_feat.device());
+  Tensor grad_feat = out_f32(outs, 0, {n, h, f}, in_feat, "grad_feat");
+  Tensor grad_attn_row = out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row");
+  Tensor grad_attn_col = out_f32(outs, 2, {n, h}, in_feat, "grad_attn_col");
+  const size_t nb = API(dgnn_gat_backward_workspace_bytes)(m, n, nnz, h, f, 1);
+  Tensor ws = workspace(nb, in_feat);
+  const int rc = API(dgnn_gat_backward_packed)(
+      m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind), ip(col_ptr), ip(row_ind),
+      ip(permute), fp(row_stat), attn_drop > 0.0 ? fp(edge_mask) : nullptr, fp(in_feat), fp(attn_col), fp(grad),
+      fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb, stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gat_backward_packed");
+  return py::cast(std::vector<Tensor>{grad_feat, grad_attn_row, grad_attn_col});
+}
+
 // ================================================================== spmm / mhsddmm / mhtranspose
 // -> out[r,h,:] = sum_j edge_val[j,h] * in_feat[colind[j],h,:]   (GE-SpMM)
 Tensor spmm_csr(const Tensor &rowptr, const Tensor &colind, const Tensor &edge_val, const Tensor &in_feat) {
@@ -633,6 +671,14 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("edge_max"), arg("edge_sum"), arg("edge_mask"), arg("in_feat"), arg("attn_row"),
       arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
+      arg("out") = py::none());
+  def(m, "gat_backward_packed", &gat_backward_packed,
+      "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat, edge_mask, in_feat, "
+      "attn_col, grad, out=None",
+      "gat_backward with row_stat [m,h,4] = {attn_row, edge_max, edge_sum, row_dot} packed per (row, head).\n"
+      "-> [grad_feat, grad_attn_row, grad_attn_col], or None where the packed kernels do not apply.",
+      arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
+      arg("permute"), arg("row_stat"), arg("edge_mask"), arg("in_feat"), arg("attn_col"), arg("grad"),
       arg("out") = py::none());
 }
 

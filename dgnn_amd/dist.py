@@ -73,6 +73,12 @@ class _NativeOps:
         return self._gat.gat_backward(slope, 0.0, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max,
                                       edge_sum, None, in_feat, attn_row, attn_col, grad, row_dot=row_dot, out=out)
 
+    def gat_backward_packed(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat, in_feat,
+                            attn_col, grad, out=None):
+        """row_stat [rows,H,4] = {attn_row, edge_max, edge_sum, row_dot}; None where unsupported."""
+        return self._gat.gat_backward_packed(slope, 0.0, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat,
+                                             None, in_feat, attn_col, grad, out=out)
+
     def transpose(self, ptr, ind, n_cols):
         """(ptr, ind) = CSR of an (r x n_cols) matrix -> (ptr_T [n_cols+1], ind_T, perm)."""
         return self._fmt.csr2csc_int(ptr, ind, n_cols=n_cols)
@@ -366,7 +372,8 @@ class PartitionedGAT:
         in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope = self._ctx
         grad_out_loc = grad_out_loc.contiguous()
         S_loc = self.ops.row_dot(grad_out_loc, out)
-        stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=1).contiguous()   # [n_loc,4,H]
+        # the 16-byte records the column-gather kernel reads per (edge, head): they travel packed
+        stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=2).contiguous()   # [n_loc,H,4]
         if self.mode == "halo":
             side = self.b_side
             grad_tab, stat_tab = self._table(side, grad_out_loc, "grad"), self._table(side, stat_loc, "stat")
@@ -374,18 +381,21 @@ class PartitionedGAT:
         else:
             grad_tab, stat_tab = self._all_gather_rows(grad_out_loc), self._all_gather_rows(stat_loc)
             handles = [[]]
-        gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(2)), dtype=stat_tab.dtype, device=stat_tab.device)
+        gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
         gf = torch.empty_like(in_feat_loc)
         gc = torch.empty_like(attn_col_loc)
         for s, (a, b, cptr, rind, n_vis, rptr, cind, perm) in enumerate(self.b_blocks):
             self._wait(handles[s])
-            stat = stat_tab[:n_vis].permute(1, 0, 2).contiguous()                         # [4,rows,H]
             # every chunk writes its own columns of grad_feat / grad_attn_col; its grad_attn_row
             # is a partial sum over the table rows it can see
-            _, gr_part, _ = self.ops.gat_backward(slope, rptr, cind, cptr, rind, perm, stat[1], stat[2],
-                                                  in_feat_loc[a:b], stat[0], attn_col_loc[a:b], grad_tab[:n_vis],
-                                                  stat[3], out=(gf[a:b], None, gc[a:b]))
-            gr_tab[:n_vis] += gr_part
+            outs = (gf[a:b], None, gc[a:b])
+            res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],
+                                               in_feat_loc[a:b], attn_col_loc[a:b], grad_tab[:n_vis], out=outs)
+            if res is None:             # shape outside the packed kernels: unpack to four [rows,H] arrays
+                stat = stat_tab[:n_vis].permute(2, 0, 1).contiguous()
+                res = self.ops.gat_backward(slope, rptr, cind, cptr, rind, perm, stat[1], stat[2], in_feat_loc[a:b],
+                                            stat[0], attn_col_loc[a:b], grad_tab[:n_vis], stat[3], out=outs)
+            gr_tab[:n_vis] += res[1]
         if self.mode == "halo":
             gr = self._return_rows(self.b_side, gr_tab)
         else:

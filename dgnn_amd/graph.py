@@ -1,0 +1,41 @@
+"""Graph index preparation on the device: the five index arrays every fused operator takes.
+
+The reference scripts build them on the host with DGL + scipy, once per graph
+(dgNN/script/train/train_gatconv.py:73-94; GMM variant train_gmmconv.py:76-89):
+  * remove, then add self loops (:75-76);
+  * ``col, row = g.edges(order='srcdst')`` (:78): ROW = destination, COL = source;
+  * ``csr_matrix((arange(E), (row, col)))`` (:82): CSR by destination, sources ascending inside a
+    row, duplicate edges merged;
+  * ``.tocsc()`` of it (:87-90) and ``permute`` = the CSR position of every CSC entry (:92-94);
+  * everything int32 on the device (:109-112).
+Here the same arrays come out of one sort of (dst, src) keys plus the device transpose
+(csrc/convert.hip), bit-identical to the scipy recipe (tests/test_gpu_parity.py).
+"""
+import torch
+
+from .native import format_conversion
+
+
+def prepare_graph(src, dst, n, self_loops="replace"):
+    """Edges src -> dst (integer tensors on the GPU, any order, duplicates allowed) of a graph
+    with ``n`` nodes -> (row_ptr, col_ind, col_ptr, row_ind, permute), all int32.
+
+    self_loops: "replace" = drop the given ones and add one per node, as the reference scripts
+    do (train_gatconv.py:75-76); "keep" = leave the edge list as it is."""
+    if src.shape != dst.shape or src.dim() != 1:
+        raise ValueError("src and dst must be 1-d tensors of the same length")
+    if self_loops not in ("replace", "keep"):
+        raise ValueError(f"self_loops must be 'replace' or 'keep', not {self_loops!r}")
+    src, dst = src.to(torch.int64), dst.to(torch.int64)
+    if src.numel() and not (0 <= int(torch.min(torch.minimum(src, dst))) and int(torch.max(torch.maximum(src, dst))) < n):
+        raise ValueError("node ids must lie in [0, n)")
+    if self_loops == "replace":
+        keep = src != dst
+        loops = torch.arange(n, dtype=torch.int64, device=src.device)
+        src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+    key = torch.unique(dst * n + src)                       # sorted: destinations, then sources
+    rows = (key // n).to(torch.int32)
+    col_ind = (key % n).to(torch.int32)
+    row_ptr = format_conversion.coo2csr(rows, n)
+    col_ptr, row_ind, permute = format_conversion.csr2csc_int(row_ptr, col_ind)
+    return row_ptr, col_ind, col_ptr, row_ind, permute

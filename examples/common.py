@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from dgnn_amd.native import format_conversion  # noqa: E402
+from dgnn_amd.graph import prepare_graph  # noqa: E402,F401
 
 # name: (nodes, directed edges before self loops, input features, classes)
 CITATION_SHAPES = {
@@ -21,18 +21,6 @@ CITATION_SHAPES = {
     "reddit": (232965, 114615892, 602, 41),
     "products": (2449029, 62000000, 100, 47),      # R-MAT of bench.py's headline shape
 }
-
-
-def prepare_graph(src, dst, n):
-    """Edges src->dst (int64 device tensors, any order, duplicates allowed) -> the five index
-    arrays every fused operator takes, built on the device: CSR by destination with ascending
-    sources, its CSC, and permute (the convention of script/train/train_gatconv.py:78-94)."""
-    key = torch.unique(dst * n + src)                       # sorted: rows, then columns
-    rows = (key // n).to(torch.int32)
-    col_ind = (key % n).to(torch.int32)
-    row_ptr = format_conversion.coo2csr(rows, n)
-    col_ptr, row_ind, permute = format_conversion.csr2csc_int(row_ptr, col_ind)
-    return row_ptr, col_ind, col_ptr, row_ind, permute
 
 
 def synthetic_citation(name, device, seed=0):
@@ -48,10 +36,7 @@ def synthetic_citation(name, device, seed=0):
     else:
         src = torch.randint(0, n, (e,), device=device, generator=gen)
         dst = torch.randint(0, n, (e,), device=device, generator=gen)
-        keep = src != dst
-        loops = torch.arange(n, device=device)
-        src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
-        graph = prepare_graph(src, dst, n)
+        graph = prepare_graph(src, dst, n)      # self loops removed then added (train_gatconv.py:75-76)
     features = torch.randn((n, n_feats), device=device, generator=gen)
     labels = torch.randint(0, n_classes, (n,), device=device, generator=gen)
     train_mask = torch.rand(n, device=device, generator=gen) < 0.3

@@ -127,6 +127,24 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
                       float *grad_attn_row, float *grad_attn_col, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* dgnn_gat_backward with the per-row inputs handed over PACKED: row_stat [m,h,4] =
+ * {attn_row, edge_max, edge_sum, row_dot} per (row, head), the 16-byte records the column-gather
+ * kernel reads per (edge, head).  dgnn_gat_backward builds this table from its four [m,h] inputs
+ * on every call; a caller that already holds it in this layout -- the row-partitioned multi-GPU
+ * runner receives exactly these records from its peers, and runs several column chunks against
+ * one table -- skips that pass.  No counterpart in the reference (its fused_backward_kernel,
+ * fused_gatconv_kernel.cu:892-968, re-gathers the four arrays per edge).  Same outputs, bit for
+ * bit, and same workspace (query with have_row_term = 1).  DGNN_ERR_UNSUPPORTED where the
+ * neighbour-grouped kernels do not apply (h > 8, wide or misaligned rows, row_stat not 16-byte
+ * aligned): unpack and call dgnn_gat_backward. */
+int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative_slope,
+                             float attn_drop, const int *row_ptr, const int *col_ind,
+                             const int *col_ptr, const int *row_ind, const int *permute,
+                             const float *row_stat, const float *edge_mask, const float *in_feat,
+                             const float *attn_col, const float *grad, float *grad_feat,
+                             float *grad_attn_row, float *grad_attn_col, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------- GE-SpMM / SDDMM / permute ---- */
 
 size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f);

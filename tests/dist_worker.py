@@ -53,6 +53,16 @@ class OracleOps:
         cp, ri, pm = self.o.csr2csc(ptr.numpy(), ind.numpy(), n_cols)
         return self._t(cp), self._t(ri), self._t(pm)
 
+    def gat_backward_packed(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat, in_feat,
+                            attn_col, grad, out=None):
+        """Stand-in for the packed entry point: odd row counts take the `None` (unsupported) way so
+        that the runner's unpacking fallback is exercised too."""
+        if row_stat.size(0) % 2 == 1:
+            return None
+        st = row_stat.permute(2, 0, 1).contiguous()
+        return self.gat_backward(slope, row_ptr, col_ind, col_ptr, row_ind, permute, st[1], st[2], in_feat,
+                                 st[0], attn_col, grad, st[3], out=out)
+
     def gat_backward(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
                      in_feat, attn_row, attn_col, grad, row_dot, out=None):
         """Same dataflow as the HIP backward: one pass over the CSC, d written to CSR order through

@@ -143,6 +143,18 @@ def test_gat_caller_provided_outputs(nat):
     assert all(torch.equal(a, b) for a, b in zip(bgot, bref))
     with pytest.raises(dgnn_amd.DgnnError):
         nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, 0.0, out=(big, None, None))
+    # packed row statistics (what the multi-GPU runner exchanges): same bits as the unpacked call
+    S = nat["gat"].gat_row_dot(go, ref[0])
+    packed = torch.stack((ar, ref[1], ref[2], S), dim=2).contiguous()
+    pgot = nat["gat"].gat_backward_packed(0.2, 0.0, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"],
+                                          G["permute"], packed, None, x, ac, go)
+    bdot = nat["gat"].gat_backward(0.2, 0.0, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                   ref[1], ref[2], None, x, ar, ac, go, row_dot=S)
+    assert pgot is not None and all(torch.equal(a, b) for a, b in zip(pgot, bdot))
+    wide = nat["gat"].gat_backward_packed(0.2, 0.0, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                          torch.zeros((g["n"], 9, 4), device=DEV), None, torch.zeros((g["n"], 9, 8), device=DEV),
+                                          torch.zeros((g["n"], 9), device=DEV), torch.zeros((g["n"], 9, 8), device=DEV))
+    assert wide is None                                   # nine heads: outside the packed kernels
 
 
 @pytest.mark.parametrize("name", ["tiny", "powerlaw256", "rmat4k"])
@@ -238,6 +250,34 @@ def test_spmm_sddmm_transpose(nat, name, h, f):
                  mass=oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], np.abs(a), np.abs(b)))
     tr = nat["tr"].mhtranspose(G["permute"], dev(val))
     assert np.array_equal(host(tr), oracle.mhtranspose(g["permute"], val)), "mhtranspose must be an exact copy"
+
+
+@pytest.mark.parametrize("self_loops", ["replace", "keep"])
+def test_prepare_graph_matches_the_reference_scipy_recipe(self_loops):
+    """dgnn_amd.graph.prepare_graph against script/train/train_gatconv.py:75-94 restated with scipy
+    (remove + add self loops, CSR by destination with merged duplicates, CSC, permute)."""
+    import scipy.sparse as sp
+    from dgnn_amd.graph import prepare_graph
+    rng = np.random.default_rng(3)
+    n, e = 300, 5000
+    src, dst = rng.integers(0, n, e), rng.integers(0, n, e)
+    src[:50], dst[:50] = src[50:100], dst[50:100]          # duplicate edges
+    dst[100:130] = src[100:130]                             # self loops in the input
+    got = [host(t) for t in prepare_graph(dev(src), dev(dst), n, self_loops)]
+    if self_loops == "replace":
+        keep = src != dst
+        src, dst = np.concatenate([src[keep], np.arange(n)]), np.concatenate([dst[keep], np.arange(n)])
+    a = sp.csr_matrix((np.ones(src.size), (dst, src)), shape=(n, n))      # row = destination, col = source
+    a.sum_duplicates()
+    a.sort_indices()
+    nnz = a.nnz
+    csr = sp.csr_matrix((np.arange(nnz), a.indices, a.indptr), shape=(n, n))
+    csc = csr.tocsc()
+    want = [a.indptr, a.indices, csc.indptr, csc.indices, csc.data]
+    for g_arr, w_arr, nm in zip(got, want, ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")):
+        assert g_arr.dtype == np.int32 and np.array_equal(g_arr, w_arr.astype(np.int32)), nm
+    with pytest.raises(ValueError):
+        prepare_graph(dev(src), dev(dst), n - 1, self_loops)
 
 
 @pytest.mark.parametrize("name", list(GRAPHS))
