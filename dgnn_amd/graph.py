@@ -27,7 +27,7 @@ def prepare_graph(src, dst, n, self_loops="replace"):
     if self_loops not in ("replace", "keep"):
         raise ValueError(f"self_loops must be 'replace' or 'keep', not {self_loops!r}")
     src, dst = src.to(torch.int64), dst.to(torch.int64)
-    if src.numel() and not (0 <= int(torch.min(torch.minimum(src, dst))) and int(torch.max(torch.maximum(src, dst))) < n):
+    if src.numel() and (min(int(src.min()), int(dst.min())) < 0 or max(int(src.max()), int(dst.max())) >= n):
         raise ValueError("node ids must lie in [0, n)")
     if self_loops == "replace":
         keep = src != dst
