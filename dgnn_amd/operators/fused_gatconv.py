@@ -4,6 +4,16 @@ import torch
 from ..native import fused_gatconv as fused_gat
 
 
+def _pad4(x):
+    """[n,h,f] -> the same rows zero-padded to a multiple of four features.  A row of 4 x 41 or
+    1 x 47 floats is not 16-byte aligned, which leaves the kernels scalar lanes (one head per walk
+    over the edges); padded to 4 x 44 / 1 x 48 the same rows move as float4 in one walk.  Zero
+    features gather, accumulate and dot to zero, so the first f features are unchanged."""
+    f = x.size(2)
+    fp = (f + 3) // 4 * 4
+    return x if fp == f else torch.nn.functional.pad(x, (0, fp - f))
+
+
 def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope,
                 in_feat, attn_drop):
     """dgNN/operators/fused_gatconv.py:6-7 (same argument order)."""
@@ -13,7 +23,9 @@ def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute,
 
 def GATConvFuse_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     """dgNN/operators/fused_gatconv.py:9-10."""
-    return fused_gat.gat_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
+    f = in_feat.size(2)
+    out = fused_gat.gat_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, _pad4(in_feat))
+    return out if out.size(2) == f else out[..., :f]
 
 
 class FusedGATFunction(torch.autograd.Function):
@@ -26,23 +38,26 @@ class FusedGATFunction(torch.autograd.Function):
                 negative_slope, in_feat, attn_drop):
         attn_row = attn_row.contiguous()
         attn_col = attn_col.contiguous()
-        in_feat = in_feat.contiguous()
+        ctx.f = in_feat.size(2)
+        in_feat = _pad4(in_feat.contiguous())          # odd widths run padded (see _pad4)
         out_feat, edge_max, edge_sum, edge_mask = fused_gat.gat_forward(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
                               edge_mask, in_feat, attn_row, attn_col, out_feat)
         ctx.negative_slope = negative_slope
         ctx.attn_drop = attn_drop
-        return out_feat
+        return out_feat if out_feat.size(2) == ctx.f else out_feat[..., :ctx.f]
 
     @staticmethod
     def backward(ctx, grad_out):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
          attn_row, attn_col, out_feat) = ctx.saved_tensors
-        grad_out = grad_out.contiguous()                       # fused_gatconv.py:26
+        grad_out = _pad4(grad_out).contiguous()                # fused_gatconv.py:26
         grad_feat, grad_attn_row, grad_attn_col = fused_gat.gat_backward(
             ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
             edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad_out, out_feat=out_feat)
+        if grad_feat.size(2) != ctx.f:
+            grad_feat = grad_feat[..., :ctx.f]
         # same tuple layout as fused_gatconv.py:34
         return grad_attn_row, grad_attn_col, None, None, None, None, None, None, grad_feat, None
 
@@ -72,22 +87,27 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
         if scores is None:                       # shape outside the kernel's range
             scores = (attn_l * feat).sum(-1), (attn_r * feat).sum(-1)
         attn_row, attn_col = scores
+        ctx.f = feat.size(2)
+        feat_p = _pad4(feat)                              # odd widths run padded (see _pad4)
         out_feat, edge_max, edge_sum, edge_mask = fused_gat.gat_forward(
-            attn_row, attn_col, row_ptr, col_ind, negative_slope, feat, attn_drop)
+            attn_row, attn_col, row_ptr, col_ind, negative_slope, feat_p, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
-                              edge_mask, feat, attn_row, attn_col, out_feat, attn_l, attn_r)
+                              edge_mask, feat, attn_row, attn_col, out_feat, attn_l, attn_r,
+                              feat_p if feat_p is not feat else None)
         ctx.negative_slope = negative_slope
         ctx.attn_drop = attn_drop
-        return out_feat
+        return out_feat if out_feat.size(2) == ctx.f else out_feat[..., :ctx.f]
 
     @staticmethod
     def backward(ctx, grad_out):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, feat,
-         attn_row, attn_col, out_feat, attn_l, attn_r) = ctx.saved_tensors
+         attn_row, attn_col, out_feat, attn_l, attn_r, feat_p) = ctx.saved_tensors
         grad_feat, g_row, g_col = fused_gat.gat_backward(
             ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
-            edge_max, edge_sum, edge_mask, feat, attn_row, attn_col, grad_out.contiguous(),
-            out_feat=out_feat)
+            edge_max, edge_sum, edge_mask, feat if feat_p is None else feat_p, attn_row, attn_col,
+            _pad4(grad_out).contiguous(), out_feat=out_feat)
+        if grad_feat.size(2) != ctx.f:
+            grad_feat = grad_feat[..., :ctx.f].contiguous()
         if ctx.fused_scores:
             g_l, g_r = _lo.attn_scores_backward(feat, attn_l, attn_r, g_row, g_col, grad_feat)
         else:

@@ -178,10 +178,12 @@ def test_gat_inference_and_tiles(nat, name):
     assert_close(host(esum), s64, "tiled edge_sum")
 
 
-def test_gat_autograd_operator_matches_explicit_backward(nat):
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 47), (4, 41), (3, 6), (2, 1)])
+def test_gat_autograd_operator_matches_explicit_backward(nat, h, f):
+    """The autograd operator; widths that are not multiples of four run zero-padded inside it
+    (operators/fused_gatconv.py::_pad4) and must come out with the caller's shapes."""
     from dgnn_amd.operators import GATConvFuse, GATConvFuse_inference
     g = GRAPHS["powerlaw256"]
-    h, f = 4, 64
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=9)
     G = gdev(g)
     x = dev(in_feat).requires_grad_()
@@ -190,9 +192,12 @@ def test_gat_autograd_operator_matches_explicit_backward(nat):
     out = GATConvFuse(ar, ac, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
                       0.2, x, 0.0)
     out.backward(dev(grad))
+    assert out.shape == (g["n"], h, f) and x.grad.shape == x.shape
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0, None)
     gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, 0.0, g["row_ptr"], g["col_ind"], None, in_feat,
                                                attn_row, attn_col, grad)
-    _, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2)
+    assert_close(host(out), o64, "autograd out_feat", mass=m_out)
     assert_close(host(x.grad), gf64, "autograd grad_feat", mass=m_gf)
     assert_close(host(ar.grad), gr64, "autograd grad_attn_row", mass=m_gr)
     assert_close(host(ac.grad), gc64, "autograd grad_attn_col", mass=m_gc)

@@ -167,9 +167,39 @@ def reddit():
                       "GBps": round((nnz * (4 * H * F + 4 * H + 4) + n * 4 * H * F) / td / 1e6, 1)}), flush=True)
 
 
+def odd_widths(workload="products"):
+    """Feature widths that are not multiples of four: the autograd operator (rows padded to the next
+    multiple of four, dgnn_amd/operators/fused_gatconv.py::_pad4) against the native module called
+    on the unpadded rows; fwd+bwd per call."""
+    from dgnn_amd.native import fused_gatconv as fg
+    from dgnn_amd.operators import GATConvFuse
+    g = bench.build_graph(workload, dev)
+    n = g["n"]
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    for H, F in ((1, 47), (4, 41), (1, 7), (3, 6), (2, 30)):
+        x = (torch.rand((n, H, F), device=dev, generator=gen) - 0.4).requires_grad_()
+        ar = (torch.rand((n, H), device=dev, generator=gen) - 0.6).requires_grad_()
+        ac = (torch.rand((n, H), device=dev, generator=gen) - 0.4).requires_grad_()
+        go = torch.rand((n, H, F), device=dev, generator=gen) - 0.5
+
+        def op():
+            x.grad = ar.grad = ac.grad = None
+            GATConvFuse(ar, ac, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], 0.2, x, 0.0).backward(go)
+
+        def native():
+            xd, ard, acd = x.detach(), ar.detach(), ac.detach()
+            out, emax, esum, emask = fg.gat_forward(ard, acd, g["row_ptr"], g["col_ind"], 0.2, xd, 0.0)
+            fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], emax, esum,
+                            emask, xd, ard, acd, go, out_feat=out)
+        print(json.dumps({"op": f"gat {workload} fwd+bwd", "H": H, "F": F, "operator_padded_ms": round(timeit(op, 3, 1), 3),
+                          "native_unpadded_ms": round(timeit(native, 3, 1), 3)}), flush=True)
+        del x, go
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["edgeconv", "gmm", "reddit"])
     a = ap.parse_args()
     for w in a.which:
-        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn, "layer": layer, "shapes": shapes}[w]()
+        {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn, "layer": layer, "shapes": shapes,
+         "odd": odd_widths}[w]()
