@@ -5,6 +5,7 @@ import torch
 from torch import nn
 
 from ..native import gat_layer_ops
+from ._project import project
 from ..operators.fused_gatconv import GATConvFuseFromFeat, GATConvFuse_inference, GATEpilogue
 
 
@@ -47,7 +48,7 @@ class GATConv(nn.Module):
             nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
 
     def forward(self, row_ptr, col_ind, col_ptr, row_ind, permute, feat):
-        h = torch.matmul(feat, self.W).view(-1, self.num_heads, self.out_feats)
+        h = project(feat, self.W).view(-1, self.num_heads, self.out_feats)
         h = self.feat_drop(h)
         # attn_l is the DESTINATION (row) term, attn_r the SOURCE term (gatconv_layer.py:74-75;
         # the opposite of DGL's naming, test/func_test/func_gat_dgl.py:62)
