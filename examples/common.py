@@ -55,6 +55,28 @@ def time_epochs(fn, n_epochs, warmup=10):
     return (time.time() - start) / n_epochs
 
 
+def capture_step(step_fn, warmup=3):
+    """One call of ``step_fn`` as a HIP graph (torch.cuda.CUDAGraph): a small-graph epoch is a few
+    dozen launches of microsecond kernels, so replaying it as ONE graph launch removes the host
+    from the loop (Cora-sized GAT training epoch: 0.83 ms eager -> 0.53 ms replayed).  The inputs
+    must be static tensors and the optimizer capturable; the library itself neither allocates nor
+    synchronises, so its launches capture as they are.  Keep random-number ops (dropout) out of the
+    captured step: capturing them aborted the process on this ROCm build.  -> (replay, value step_fn returned during
+    capture: static tensors that every replay overwrites)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            step_fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        result = step_fn()
+    torch.cuda.synchronize()
+    return graph.replay, result
+
+
 def max_memory_mb(device):
     return int(torch.cuda.max_memory_allocated(device) // (1 << 20))
 

@@ -9,7 +9,7 @@ import argparse
 import torch
 from torch import nn
 
-from common import accuracy, append_csv, max_memory_mb, synthetic_citation, time_epochs
+from common import accuracy, append_csv, capture_step, max_memory_mb, synthetic_citation, time_epochs
 from dgnn_amd.layers import GATConv
 
 
@@ -48,7 +48,13 @@ def main():
     ap.add_argument("--negative-slope", type=float, default=0.2)
     ap.add_argument("--attn-drop", type=float, default=0.)
     ap.add_argument("--output", default=None)
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="capture the training epoch into a HIP graph and replay it (launch-bound small graphs)")
     args = ap.parse_args()
+    if args.hip_graph and (args.dropout != 0 or args.attn_drop != 0):
+        # checked before anything touches the GPU: capturing the dropout generators aborted the
+        # process and faulted the card on this ROCm build
+        ap.error("--hip-graph needs --dropout 0 and --attn-drop 0: random-number ops are not captured")
     print(args)
 
     device = torch.device(f"cuda:{args.gpu}")
@@ -60,31 +66,42 @@ def main():
                 feat_drop=args.dropout, attn_drop=args.attn_drop,
                 negative_slope=args.negative_slope).to(device)
     loss_fcn = nn.CrossEntropyLoss()
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
+                                 capturable=args.hip_graph)
     feats, labels = data["features"], data["labels"]
     train_idx = data["train_mask"].nonzero().squeeze(1)      # index list: no host sync inside the epoch
     train_labels = labels[train_idx]
     losses = []
 
-    def train_epoch():
+    def train_step():
         loss = loss_fcn(model(feats)[train_idx], train_labels)
-        optimizer.zero_grad()
+        optimizer.zero_grad(set_to_none=not args.hip_graph)
         loss.backward()
         optimizer.step()
-        losses.append(loss.detach())
+        return loss.detach()
+
+    def train_epoch():
+        losses.append(train_step())
 
     def infer_epoch():
         with torch.no_grad():
             return model(feats)
 
     model.train()
-    train_time = time_epochs(train_epoch, args.n_epochs)
+    if args.hip_graph:
+        losses.append(train_step().clone())
+        replay, static_loss = capture_step(train_step)
+        train_time = time_epochs(replay, args.n_epochs)
+        losses.append(static_loss.clone())
+    else:
+        train_time = time_epochs(train_epoch, args.n_epochs)
     model.eval()
     inference_time = time_epochs(infer_epoch, args.n_epochs, warmup=0)
     acc = accuracy(infer_epoch()[data["test_mask"]], labels[data["test_mask"]])
     print(f"loss {losses[0].item():.4f} -> {losses[-1].item():.4f}; test accuracy {acc:.4f} (random labels)")
-    append_csv(args.output, "train_GAT_dgnn_amd,{} heads={} hidden_dim={},{:f}s,{:f}s,{}MB,{}".format(
-        args.dataset, args.n_heads, args.n_hidden, train_time, inference_time, max_memory_mb(device), acc))
+    append_csv(args.output, "train_GAT_dgnn_amd,{} heads={} hidden_dim={}{},{:f}s,{:f}s,{}MB,{}".format(
+        args.dataset, args.n_heads, args.n_hidden, " hip-graph" if args.hip_graph else "", train_time,
+        inference_time, max_memory_mb(device), acc))
 
 
 if __name__ == "__main__":

@@ -42,3 +42,22 @@ def test_dgcnn_example(tmp_path):
                             "--n-epochs", "20", "--lr", "0.01", "--dropout", "0", tmp_path=tmp_path)
     assert cols[0] == "train_edgeconv_dgnn_amd" and cols[1] == "4 10" and len(cols) == 6
     assert last < first
+
+
+def test_hip_graph_flag_refuses_dropout_before_touching_the_gpu(tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_gatconv.py"), "--hip-graph"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "--dropout 0" in p.stderr
+
+
+@pytest.mark.skipif(os.environ.get("DGNN_TEST_HIP_GRAPH") != "1",
+                    reason="graph capture of a whole training step: run on request (DGNN_TEST_HIP_GRAPH=1)")
+def test_gat_and_monet_examples_replayed_from_a_hip_graph(tmp_path):
+    """--hip-graph: the training epoch captured once and replayed; it still trains."""
+    cols, first, last = run("train_gatconv.py", "--dataset", "cora", "--n-heads", "4", "--n-hidden", "64",
+                            "--n-epochs", "30", "--lr", "0.01", "--dropout", "0", "--hip-graph", tmp_path=tmp_path)
+    assert cols[1] == "cora heads=4 hidden_dim=64 hip-graph" and last < first
+    (tmp_path / "result.csv").unlink()
+    cols, first, last = run("train_gmmconv.py", "--dataset", "cora", "--n-hidden", "64", "--n-epochs", "30",
+                            "--dropout", "0", "--hip-graph", tmp_path=tmp_path)
+    assert cols[1].endswith("hip-graph") and last < first
