@@ -1,0 +1,18 @@
+"""Feature rows padded to a multiple of four floats for the autograd operators."""
+import torch
+
+
+def pad4(x):
+    """[n,h,f] -> the same rows zero-padded to the next multiple of four features.  A row of
+    4 x 41 or 1 x 47 floats is not 16-byte aligned, which leaves the kernels scalar lanes (one
+    head per walk over the edges, and the one-pass backward out of range for three 41-wide
+    kernels); padded to 4 x 44 / 1 x 48 the same rows move as float4 in one walk.  Zero features
+    gather, accumulate and dot to zero, so the first f features are unchanged."""
+    f = x.size(2)
+    fp = (f + 3) // 4 * 4
+    return x if fp == f else torch.nn.functional.pad(x, (0, fp - f))
+
+
+def unpad(x, f):
+    """View of the first f features (the caller's width)."""
+    return x if x.size(2) == f else x[..., :f]

@@ -2,16 +2,7 @@
 import torch
 
 from ..native import fused_gatconv as fused_gat
-
-
-def _pad4(x):
-    """[n,h,f] -> the same rows zero-padded to a multiple of four features.  A row of 4 x 41 or
-    1 x 47 floats is not 16-byte aligned, which leaves the kernels scalar lanes (one head per walk
-    over the edges); padded to 4 x 44 / 1 x 48 the same rows move as float4 in one walk.  Zero
-    features gather, accumulate and dot to zero, so the first f features are unchanged."""
-    f = x.size(2)
-    fp = (f + 3) // 4 * 4
-    return x if fp == f else torch.nn.functional.pad(x, (0, fp - f))
+from ._pad import pad4 as _pad4
 
 
 def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope,

@@ -4,6 +4,7 @@ import torch
 from ..native import fused_gmmconv as gmm
 from ..native import mhsddmm
 from ..native import mhtranspose
+from ._pad import pad4, unpad
 
 
 def GmmConvFuse(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
@@ -21,16 +22,17 @@ class GmmFuseFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
-        node_feat, pseudo = node_feat.contiguous(), pseudo.contiguous()
+        ctx.f = node_feat.size(2)
+        node_feat, pseudo = pad4(node_feat.contiguous()), pseudo.contiguous()   # odd widths run padded
         mu, sigma = mu.contiguous(), sigma.contiguous()
         out = gmm.gmmconv(rowptr, colind, node_feat, pseudo, mu, sigma)
         ctx.save_for_backward(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma)
-        return out
+        return unpad(out, ctx.f)
 
     @staticmethod
     def backward(ctx, grad_out):
         rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
+        grad_out = pad4(grad_out).contiguous()
         # one gather pass over the CSC yields both the feature gradient and the Gaussian
         # gradient; shapes outside its range take the reference's three-call sequence
         fused = gmm.gmm_backward_fused(colptr, rowind, permute, node_feat, pseudo, mu, sigma, grad_out)
@@ -41,4 +43,4 @@ class GmmFuseFunction(torch.autograd.Function):
             pseudo_tran = mhtranspose.mhtranspose(permute, pseudo)
             node_feat_grad = gmm.gmmconv(colptr, rowind, grad_out, pseudo_tran, mu, sigma)
         pseudo_out, mu_out, sigma_out = gmm.GaussianBp(pseudo, mu, sigma, gaussian_grad)
-        return None, None, None, None, None, node_feat_grad, pseudo_out, mu_out, sigma_out
+        return None, None, None, None, None, unpad(node_feat_grad, ctx.f), pseudo_out, mu_out, sigma_out

@@ -344,11 +344,13 @@ def test_gmm(nat, name, k, d, f):
     assert_close(host(fused[1]), want_gauss, "fused gmm backward: grad_gauss", mass=mass_gauss)
 
 
-def test_gmm_autograd_operator(nat):
+@pytest.mark.parametrize("f", [16, 41, 7])
+def test_gmm_autograd_operator(nat, f):
+    """Widths that are not multiples of four run zero-padded inside the operator (_pad.py)."""
     from dgnn_amd.operators import GmmConvFuse
     g = GRAPHS["powerlaw256"]
     G = gdev(g)
-    k, d, f = 3, 2, 16
+    k, d = 3, 2
     rng = np.random.default_rng(4)
     node_feat = rng.standard_normal((g["n"], k, f)).astype(np.float32)
     pseudo = rng.random((g["nnz"], d), dtype=np.float32)
@@ -368,6 +370,7 @@ def test_gmm_autograd_operator(nat):
     gauss = torch.exp(-0.5 * (((PS[:, None, :] - M[None]) * SG[None]) ** 2).sum(-1))
     ref = torch.zeros_like(X).index_add(0, row, gauss[:, :, None] * X[col])
     ref.backward(torch.tensor(go, dtype=torch.float64))
+    assert out.shape == (g["n"], k, f) and x.grad.shape == x.shape
     assert_close(host(out), ref.detach().numpy(), "gmm out", atol=1e-5)
     assert_close(host(x.grad), X.grad.numpy(), "gmm grad node_feat", atol=1e-5)
     assert_close(host(ps.grad), PS.grad.numpy(), "gmm grad pseudo", rtol=1e-4, atol=1e-5)
@@ -486,3 +489,28 @@ def test_graph_without_edges(nat, n, h, f):
     assert nat["sddmm"].mhsddmm(row_ptr, empty_i, grad, x).shape == (0, h)
     cp, ri, pm = nat["fmt"].csr2csc_int(row_ptr, empty_i)
     assert cp.tolist() == [0] * (n + 1) and ri.numel() == 0 and pm.numel() == 0
+
+
+@pytest.mark.parametrize("h,f", [(2, 16), (3, 41), (1, 7)])
+def test_spmm_autograd_operator(nat, h, f):
+    """GE-SpMM as an autograd operator (odd widths padded inside it) against float64 torch autograd."""
+    from dgnn_amd.operators.spmm import SpMMCsr
+    g = GRAPHS["powerlaw256"]
+    G = gdev(g)
+    rng = np.random.default_rng(8)
+    val = rng.standard_normal((g["nnz"], h)).astype(np.float32)
+    feat = rng.standard_normal((g["n"], h, f)).astype(np.float32)
+    go = rng.standard_normal((g["n"], h, f)).astype(np.float32)
+    v, x = dev(val).requires_grad_(), dev(feat).requires_grad_()
+    out = SpMMCsr(G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], v, x)
+    out.backward(dev(go))
+    row = torch.from_numpy(np.repeat(np.arange(g["n"]), np.diff(g["row_ptr"]))).long()
+    col = torch.from_numpy(g["col_ind"]).long()
+    V = torch.tensor(val, dtype=torch.float64, requires_grad=True)
+    X = torch.tensor(feat, dtype=torch.float64, requires_grad=True)
+    ref = torch.zeros_like(X).index_add(0, row, V[:, :, None] * X[col])
+    ref.backward(torch.tensor(go, dtype=torch.float64))
+    assert out.shape == (g["n"], h, f) and x.grad.shape == x.shape
+    assert_close(host(out), ref.detach().numpy(), "spmm out", atol=1e-5)
+    assert_close(host(x.grad), X.grad.numpy(), "spmm grad feat", atol=1e-5)
+    assert_close(host(v.grad), V.grad.numpy(), "spmm grad val", atol=1e-5)
