@@ -46,6 +46,6 @@ class _Project(torch.autograd.Function):
 
 def project(feat, weight):
     """feat [N, in] @ weight [in, out] (2-d inputs; anything else falls back to torch.matmul)."""
-    if feat.dim() != 2 or weight.dim() != 2:
-        return torch.matmul(feat, weight)
+    if feat.dim() != 2 or weight.dim() != 2 or feat.size(0) < _SPLIT_MIN_ROWS:
+        return torch.matmul(feat, weight)          # small inputs: nothing to split, plain autograd
     return _Project.apply(feat, weight)

@@ -1,6 +1,10 @@
 """Feature rows padded to a multiple of four floats for the autograd operators."""
 import torch
 
+# Below this many rows a call is bound by launch latency, not by how its lanes move the rows:
+# the two extra copies would only add launches (Cora-sized graphs).
+PAD_MIN_ROWS = 1 << 15
+
 
 def pad4(x):
     """[n,h,f] -> the same rows zero-padded to the next multiple of four features.  A row of
@@ -10,7 +14,9 @@ def pad4(x):
     gather, accumulate and dot to zero, so the first f features are unchanged."""
     f = x.size(2)
     fp = (f + 3) // 4 * 4
-    return x if fp == f else torch.nn.functional.pad(x, (0, fp - f))
+    if fp == f or x.size(0) < PAD_MIN_ROWS:
+        return x
+    return torch.nn.functional.pad(x, (0, fp - f))
 
 
 def unpad(x, f):

@@ -178,10 +178,18 @@ def test_gat_inference_and_tiles(nat, name):
     assert_close(host(esum), s64, "tiled edge_sum")
 
 
+@pytest.fixture(params=[0, 1 << 30], ids=["padded", "as-is"])
+def pad_rows(request, monkeypatch):
+    """Odd widths run zero-padded above PAD_MIN_ROWS rows (operators/_pad.py): both ways here."""
+    import dgnn_amd.operators._pad as pad
+    monkeypatch.setattr(pad, "PAD_MIN_ROWS", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("h,f", [(4, 64), (1, 47), (4, 41), (3, 6), (2, 1)])
-def test_gat_autograd_operator_matches_explicit_backward(nat, h, f):
+def test_gat_autograd_operator_matches_explicit_backward(nat, h, f, pad_rows):
     """The autograd operator; widths that are not multiples of four run zero-padded inside it
-    (operators/fused_gatconv.py::_pad4) and must come out with the caller's shapes."""
+    (operators/_pad.py) and must come out with the caller's shapes."""
     from dgnn_amd.operators import GATConvFuse, GATConvFuse_inference
     g = GRAPHS["powerlaw256"]
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=9)
@@ -345,7 +353,7 @@ def test_gmm(nat, name, k, d, f):
 
 
 @pytest.mark.parametrize("f", [16, 41, 7])
-def test_gmm_autograd_operator(nat, f):
+def test_gmm_autograd_operator(nat, f, pad_rows):
     """Widths that are not multiples of four run zero-padded inside the operator (_pad.py)."""
     from dgnn_amd.operators import GmmConvFuse
     g = GRAPHS["powerlaw256"]
@@ -492,7 +500,7 @@ def test_graph_without_edges(nat, n, h, f):
 
 
 @pytest.mark.parametrize("h,f", [(2, 16), (3, 41), (1, 7)])
-def test_spmm_autograd_operator(nat, h, f):
+def test_spmm_autograd_operator(nat, h, f, pad_rows):
     """GE-SpMM as an autograd operator (odd widths padded inside it) against float64 torch autograd."""
     from dgnn_amd.operators.spmm import SpMMCsr
     g = GRAPHS["powerlaw256"]
