@@ -77,7 +77,7 @@ def test_partitioned_gat_cpu_gloo(world, exchange):
     check(run_world(world, "cpu", spec, h, f, exchange), spec, h, f)
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2), (2, 6)])
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2), (2, 6), (8, 4)])
 def test_partitioned_gat_cpu_gloo_chunked_pipeline(world, chunks):
     """The chunked exchange (default 4 chunks above) with 1, 2 and 6 chunks: same result."""
     spec, h, f = (10, 700, 6000, 5), 2, 8
