@@ -20,6 +20,7 @@ _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/dgnn_hip.h declares.
 SIGNATURES = {
@@ -34,6 +35,9 @@ SIGNATURES = {
     "dgnn_gat_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 17 + [_vp, _sz, _vp]),
     "dgnn_gat_backward_packed": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 13 + [_vp, _sz, _vp]),
+    "dgnn_dropout_mask": (_i, [_i, _i, _u64, _u64, _vp, _vp]),
+    "dgnn_gat_forward_seeded": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_u64, _u64] + [_vp] * 3 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward_seeded": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_u64, _u64] + [_vp] * 9 + [_vp, _sz, _vp]),
     "dgnn_spmm_csr_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_spmm_csr": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_mhsddmm": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp]),

@@ -106,6 +106,44 @@ __device__ __forceinline__ float drop_scale(float w, float attn_drop) {
   return (float)((double)w / (1.0 - (double)attn_drop));
 }
 
+// ---- counter-based dropout mask ----------------------------------------------------------
+// The reference draws edge_mask [nnz,h] ~ U(0,1] with cuRAND on every forward and keeps it for
+// the backward (fused_gatconv_kernel.cu:333-341; 1 GB at the products shape).  Here element i of
+// the (virtual) row-major mask is component i % 4 of Philox4x32-10 at counter (i / 4, offset)
+// under key `seed`: the forward (CSR position), the CSC backward (through permute) and the
+// materialising kernel of dgnn_dropout_mask regenerate identical values, nothing is stored.
+struct DropRng {
+  unsigned long long seed, offset;
+  int on;
+};
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+// 24 random bits -> (0, 1], exactly representable: never 0, so `mask > attn_drop` keeps
+// everything at attn_drop = 0 like the reference's (0,1] floats.
+__device__ __forceinline__ float bits_to_unit(unsigned x) { return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f); }
+// mask elements 4*block .. 4*block+3
+__device__ __forceinline__ float4 drop_uniform4(const DropRng &r, unsigned long long block) {
+  const uint4 v = philox4x32_10(make_uint4((unsigned)block, (unsigned)(block >> 32), (unsigned)r.offset,
+                                           (unsigned)(r.offset >> 32)),
+                                make_uint2((unsigned)r.seed, (unsigned)(r.seed >> 32)));
+  return make_float4(bits_to_unit(v.x), bits_to_unit(v.y), bits_to_unit(v.z), bits_to_unit(v.w));
+}
+// mask element i
+__device__ __forceinline__ float drop_uniform(const DropRng &r, unsigned long long i) {
+  const float4 v = drop_uniform4(r, i >> 2);
+  const unsigned c = (unsigned)i & 3u;
+  return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+}
+
 // Gaussian mixture weight of one (edge, kernel) pair.
 __device__ __forceinline__ float gmm_weight(int dim, const float *__restrict__ ps,
                                             const float *__restrict__ mu,

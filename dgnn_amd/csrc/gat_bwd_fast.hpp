@@ -39,6 +39,7 @@ struct BwdParams {
   const int *col_ptr, *row_ind, *permute;
   const float *attn_row, *attn_col, *edge_max, *edge_sum, *edge_mask;
   const float *in_feat, *grad, *out_feat;
+  DropRng rng;         // dropout mask regenerated from (seed, offset) instead of edge_mask
   const float *S_in;   // optional precomputed row dots [m,H]
   float4 *rowstat;     // [m][H] {attn_row, edge_max, edge_sum, S}
   float *dE;           // [nnz][H] in CSR order
@@ -242,7 +243,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         }
         continue;
       }
-      const int pos = (P.edge_mask != nullptr) ? P.permute[e0 + p] : 0;
+      const bool drop = (P.edge_mask != nullptr) || P.rng.on;
+      const int pos = drop ? P.permute[e0 + p] : 0;
       float ac[HC];
       if (HC == 4 && H == 4) {
         const float4 a4 = *(const float4 *)(P.attn_col + (size_t)c * 4);
@@ -258,8 +260,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         const float e = leaky_relu(s4.x + ac[h], P.slope);
         const float a = expf(e - s4.y) / s4.z;                 // :747
         float w = a;
-        if (P.edge_mask != nullptr) {
-          if (!(P.edge_mask[(size_t)pos * H + h] > P.attn_drop)) w = 0.f;    // :738
+        if (drop) {
+          const float mk = P.rng.on ? drop_uniform(P.rng, (unsigned long long)pos * H + h)
+                                    : P.edge_mask[(size_t)pos * H + h];
+          if (!(mk > P.attn_drop)) w = 0.f;                                  // :738
           w = w / (1 - P.attn_drop);                                         // :749 (float divide)
         }
         const bool neg = e < 0.f;                                            // :953

@@ -128,7 +128,7 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
                    const float *attn_row, const float *attn_col, const int *row_ptr,
                    const int *col_ind, const float *in_feat, const float *edge_mask,
                    float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                   size_t workspace_bytes, hipStream_t st) {
+                   size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0}) {
   if (m == 0) return DGNN_OK;
   // the H == 4 kernels move the per-row / per-edge scalars as float4
   const bool h4_aligned = aligned16(attn_col) && aligned16(attn_row) && aligned16(edge_mask) &&
@@ -138,10 +138,11 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
     P.m = m; P.nnz = nnz; P.H = h; P.F = f;
     P.attn_drop = attn_drop; P.slope = slope;
     P.row_ptr = row_ptr; P.col_ind = col_ind;
-    P.attn_row = attn_row; P.attn_col = attn_col; P.edge_mask = edge_mask;
+    P.attn_row = attn_row; P.attn_col = attn_col; P.edge_mask = edge_mask; P.rng = rng;
     P.in_feat = in_feat; P.edge_max = edge_max; P.edge_sum = edge_sum; P.out = out_feat;
     return launch_fast_gather<MODE_GAT>(P, workspace, workspace_bytes, st);
   }
+  if (rng.on) return DGNN_ERR_UNSUPPORTED;   // the wave-per-row kernels read a materialised mask
   hipLaunchKernelGGL(k_gat_fwd_row, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, m, h, f,
                      attn_drop, slope, attn_row, attn_col, row_ptr, col_ind, in_feat, edge_mask,
                      edge_max, edge_sum, out_feat);
@@ -330,7 +331,8 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
                              const float *attn_row, const float *attn_col, const float *grad,
                              const float *out_feat, const float *row_dot, const float4 *packed,
                              float *grad_feat, float *grad_attn_row, float *grad_attn_col,
-                             void *workspace, size_t workspace_bytes, void *stream) {
+                             void *workspace, size_t workspace_bytes, void *stream,
+                             DropRng rng = DropRng{0, 0, 0}) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (n < 0) return DGNN_ERR_BAD_ARG;
@@ -340,12 +342,13 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
   if (n > 0 && (!in_feat || !attn_col || !grad_feat || !grad_attn_col)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && (!col_ind || !row_ind || !permute)) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
-  if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
+  if (attn_drop > 0.f && nnz > 0 && !edge_mask && !rng.on) return DGNN_ERR_BAD_ARG;
+  if (!(attn_drop > 0.f)) rng.on = 0;
   const bool have_row_term = (out_feat != nullptr) || (row_dot != nullptr) || (packed != nullptr) || m == 0;
   BwdLayout w = bwd_layout(m, n, nnz, h, f, !have_row_term);
   if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const float *mask = attn_drop > 0.f ? edge_mask : nullptr;
+  const float *mask = (attn_drop > 0.f && !rng.on) ? edge_mask : nullptr;
   char *ws = (char *)workspace;
   float *S = (float *)(ws + w.off_S);
   float *dE = (float *)(ws + w.off_dE);
@@ -355,7 +358,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     float *tmp = (float *)(ws + w.off_out);
     rc = launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
                         col_ind, in_feat, mask, nullptr, nullptr, tmp, ws + w.off_fwd,
-                        w.total - w.off_fwd, st);
+                        w.total - w.off_fwd, st, rng);
     if (rc) return rc;
     out = tmp;
   }
@@ -365,6 +368,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
               (vec == 1 || (aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
                             (out == nullptr || aligned16(out))));
   if (packed != nullptr && !(fast && aligned16(packed))) return DGNN_ERR_UNSUPPORTED;
+  if (rng.on && !fast) return DGNN_ERR_UNSUPPORTED;   // the wave-per-column kernel reads a materialised mask
   if (fast) {
     BwdParams P = {};
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
@@ -374,7 +378,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.attn_drop = attn_drop; P.slope = negative_slope;
     P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
     P.attn_row = attn_row; P.attn_col = attn_col; P.edge_max = edge_max; P.edge_sum = edge_sum;
-    P.edge_mask = mask; P.in_feat = in_feat; P.grad = grad; P.out_feat = out;
+    P.edge_mask = mask; P.rng = rng; P.in_feat = in_feat; P.grad = grad; P.out_feat = out;
     P.S_in = row_dot;
     P.rowstat = packed ? const_cast<float4 *>(packed) : (float4 *)(ws + w.off_stat);
     P.dE = dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
@@ -478,6 +482,62 @@ int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative
                            permute, nullptr, nullptr, edge_mask, in_feat, nullptr, attn_col, grad, nullptr,
                            nullptr, (const float4 *)row_stat, grad_feat, grad_attn_row, grad_attn_col,
                            workspace, workspace_bytes, stream);
+}
+
+// Materialise the mask the seeded entry points regenerate (one thread per Philox block of four).
+__global__ void k_dropout_mask(long long total, DropRng rng, float *__restrict__ mask) {
+  for (long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x; b * 4 < total;
+       b += (long long)gridDim.x * blockDim.x) {
+    const float4 v = drop_uniform4(rng, (unsigned long long)b);
+    const float a[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < 4 && b * 4 + i < total; ++i) mask[b * 4 + i] = a[i];
+  }
+}
+
+int dgnn_dropout_mask(int nnz, int h, uint64_t seed, uint64_t offset, float *mask, void *stream) {
+  if (nnz < 0 || h <= 0) return DGNN_ERR_BAD_ARG;
+  const long long total = (long long)nnz * h;
+  if (total == 0) return DGNN_OK;
+  if (!mask) return DGNN_ERR_BAD_ARG;
+  long long g = ((total + 3) / 4 + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, total,
+                     DropRng{seed, offset, 1}, mask);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_gat_forward_seeded(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                            const float *attn_row, const float *attn_col, const int *row_ptr,
+                            const int *col_ind, const float *in_feat, uint64_t seed, uint64_t offset,
+                            float *edge_max, float *edge_sum, float *out_feat, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (m == 0) return DGNN_OK;
+  if (!attn_row || !row_ptr || !out_feat || !edge_max || !edge_sum) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!attn_col || !in_feat || !col_ind)) return DGNN_ERR_BAD_ARG;
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+    return DGNN_ERR_WORKSPACE;
+  return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr, col_ind,
+                        in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, workspace_bytes,
+                        (hipStream_t)stream, DropRng{seed, offset, attn_drop > 0.f ? 1 : 0});
+}
+
+int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative_slope,
+                             float attn_drop, const int *row_ptr, const int *col_ind,
+                             const int *col_ptr, const int *row_ind, const int *permute,
+                             const float *edge_max, const float *edge_sum, uint64_t seed,
+                             uint64_t offset, const float *in_feat, const float *attn_row,
+                             const float *attn_col, const float *grad, const float *out_feat,
+                             const float *row_dot, float *grad_feat, float *grad_attn_row,
+                             float *grad_attn_col, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+  return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
+                           permute, edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, out_feat,
+                           row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
+                           workspace_bytes, stream, DropRng{seed, offset, 1});
 }
 
 // ------------------------------------------------------------------------- GE-SpMM / GMM

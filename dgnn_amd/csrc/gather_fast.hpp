@@ -47,6 +47,7 @@ struct GatherParams {
   const int *row_ptr, *col_ind;
   const float *attn_row, *attn_col;  // GAT
   const float *edge_mask;            // GAT dropout mask or NULL
+  DropRng rng;                       // or: the mask regenerated from (seed, offset)
   const float *edge_val;             // SpMM values [nnz,H]
   const float *pseudo, *mu, *inv_sigma;  // GMM
   const float *in_feat;
@@ -257,9 +258,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             float w[HTA];
 #pragma unroll
             for (int h = 0; h < HTA; ++h) w[h] = whole ? pe[h] / sm[h] : pe[h];              // :102
-            if (P.edge_mask != nullptr) {
+            if (P.edge_mask != nullptr || P.rng.on) {
               float mk[HTA];
-              ld_heads<HTA>(mk, P.edge_mask + (size_t)(e0 + p) * HTA);
+              if (P.rng.on) {
+#pragma unroll
+                for (int h = 0; h < HTA; ++h) mk[h] = drop_uniform(P.rng, (unsigned long long)(e0 + p) * HTA + h);
+              } else {
+                ld_heads<HTA>(mk, P.edge_mask + (size_t)(e0 + p) * HTA);
+              }
 #pragma unroll
               for (int h = 0; h < HTA; ++h) {
                 if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
@@ -309,8 +315,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           if (live) {
             float4 w4 = pe;
             if (whole) { w4.x /= sm.x; w4.y /= sm.y; w4.z /= sm.z; w4.w /= sm.w; }   // :102
-            if (P.edge_mask != nullptr) {
-              const float4 mk = *(const float4 *)(P.edge_mask + (size_t)(e0 + p) * 4);
+            if (P.edge_mask != nullptr || P.rng.on) {
+              const float4 mk = P.rng.on ? drop_uniform4(P.rng, (unsigned long long)(e0 + p))
+                                         : *(const float4 *)(P.edge_mask + (size_t)(e0 + p) * 4);
               if (!(mk.x > P.attn_drop)) w4.x = 0.f;                                 // :95
               if (!(mk.y > P.attn_drop)) w4.y = 0.f;
               if (!(mk.z > P.attn_drop)) w4.z = 0.f;
@@ -348,8 +355,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             for (int p = a + lane; p < b; p += DGNN_WAVE) {
               float w = sc[(size_t)p * H + h];
               if (whole) w = w / sm;                       // exp(e-max)/sum per edge, :102
-              if (P.edge_mask != nullptr) {
-                if (!(P.edge_mask[(size_t)(e0 + p) * H + h] > P.attn_drop)) w = 0.f;   // :95
+              if (P.edge_mask != nullptr || P.rng.on) {
+                const float mk = P.rng.on ? drop_uniform(P.rng, (unsigned long long)(e0 + p) * H + h)
+                                          : P.edge_mask[(size_t)(e0 + p) * H + h];
+                if (!(mk > P.attn_drop)) w = 0.f;   // :95
                 w = drop_scale(w, P.attn_drop);                                       // :104
               }
               sc[(size_t)p * H + h] = w;
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   // With a dropout mask a dropped (edge, head) has weight exactly 0: its lanes skip the load,
   // so the dropped share of the feature traffic never leaves HBM (the reference loads the row
   // and multiplies by 0, fused_gatconv_kernel.cu:95-117; identical for finite features).
-  const bool skip0 = (MODE == MODE_GAT) && (P.edge_mask != nullptr);
+  const bool skip0 = (MODE == MODE_GAT) && (P.edge_mask != nullptr || P.rng.on);
   for (int fb = 0; fb < nfb; ++fb) {
     bool active[NS];
     size_t lane_off[NS];

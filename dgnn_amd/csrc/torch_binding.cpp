@@ -294,6 +294,79 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
   return {grad_feat, grad_attn_row, grad_attn_col};
 }
 
+// ---- dropout without a stored mask (include/dgnn_hip.h: dgnn_*_seeded) ----------------------
+// -> the [nnz,h] mask the seeded entry points regenerate from (seed, offset)
+Tensor dropout_mask(int64_t nnz, int64_t h, uint64_t seed, uint64_t offset, const Tensor &like) {
+  if (!like.defined() || !like.is_cuda()) fail("like must be a GPU tensor (dgnn_amd has no CPU path)");
+  c10::DeviceGuard guard(like.device());
+  Tensor mask = new_f32({nnz, h}, like);
+  check_rc(API(dgnn_dropout_mask)(as_int(nnz, "nnz"), as_int(h, "heads"), seed, offset, fo(mask), stream_of(like)),
+           "dgnn_dropout_mask");
+  return mask;
+}
+
+// gat_forward with the dropout mask regenerated from (seed, offset) instead of drawn and stored.
+// -> [out_feat, edge_max, edge_sum], or None where the seeded kernels do not apply (the caller
+// materialises the same mask with dropout_mask and takes gat_forward).
+py::object gat_forward_seeded(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
+                              const Tensor &col_ind, double negative_slope, const Tensor &in_feat, double attn_drop,
+                              uint64_t seed, uint64_t offset, const OutList &outs) {
+  const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
+  c10::DeviceGuard guard(in_feat.device());
+  Tensor out = out_f32(outs, 0, {d.m, d.h, d.f}, in_feat, "out_feat");
+  Tensor edge_max = out_f32(outs, 1, {d.m, d.h}, in_feat, "edge_max");
+  Tensor edge_sum = out_f32(outs, 2, {d.m, d.h}, in_feat, "edge_sum");
+  const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
+  Tensor ws = workspace(nb, in_feat);
+  const int rc = API(dgnn_gat_forward_seeded)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
+                                              fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), seed,
+                                              offset, fo(edge_max), fo(edge_sum), fo(out), ptr<void>(ws), nb,
+                                              stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gat_forward_seeded");
+  return py::cast(std::vector<Tensor>{out, edge_max, edge_sum});
+}
+
+// gat_backward with (seed, offset) in place of edge_mask.  -> [grad_feat, grad_attn_row,
+// grad_attn_col] or None (see gat_forward_seeded).
+py::object gat_backward_seeded(double negative_slope, double attn_drop, const Tensor &row_ptr, const Tensor &col_ind,
+                               const Tensor &col_ptr, const Tensor &row_ind, const Tensor &permute,
+                               const Tensor &edge_max, const Tensor &edge_sum, uint64_t seed, uint64_t offset,
+                               const Tensor &in_feat, const Tensor &attn_row, const Tensor &attn_col,
+                               const Tensor &grad, const OptTensor &out_feat, const OptTensor &row_dot,
+                               const OutList &outs) {
+  i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
+  i32(permute, "permute");
+  f32(edge_max, "edge_max", 2), f32(edge_sum, "edge_sum", 2), f32(in_feat, "in_feat", 3);
+  f32(attn_row, "attn_row", 2), f32(attn_col, "attn_col", 2), f32(grad, "grad", 3);
+  const int m = as_int(row_ptr.size(0) - 1, "rows"), nnz = as_int(col_ind.size(0), "nnz");
+  const int n = as_int(col_ptr.size(0) - 1, "columns");
+  const int h = as_int(in_feat.size(1), "heads"), f = as_int(in_feat.size(2), "features");
+  if (in_feat.size(0) != n || attn_col.size(0) != n)
+    fail("gat_backward_seeded: in_feat/attn_col rows must equal len(col_ptr)-1");
+  if (grad.size(0) != m || attn_row.size(0) != m || edge_max.size(0) != m || edge_sum.size(0) != m)
+    fail("gat_backward_seeded: grad/attn_row/edge_max/edge_sum rows must equal len(row_ptr)-1");
+  if (grad.size(1) != h || grad.size(2) != f) fail("gat_backward_seeded: grad must be [m,h,f]");
+  if (row_ind.size(0) != nnz || permute.size(0) != nnz) fail("gat_backward_seeded: row_ind / permute must hold nnz entries");
+  if (given(out_feat)) f32(*out_feat, "out_feat", 3);
+  if (given(row_dot)) f32(*row_dot, "row_dot", 2);
+  const int have = (given(out_feat) || given(row_dot)) ? 1 : 0;
+  c10::DeviceGuard guard(in_feat.device());
+  Tensor grad_feat = out_f32(outs, 0, {n, h, f}, in_feat, "grad_feat");
+  Tensor grad_attn_row = out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row");
+  Tensor grad_attn_col = out_f32(outs, 2, {n, h}, in_feat, "grad_attn_col");
+  const size_t nb = API(dgnn_gat_backward_workspace_bytes)(m, n, nnz, h, f, have);
+  Tensor ws = workspace(nb, in_feat);
+  const int rc = API(dgnn_gat_backward_seeded)(
+      m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind), ip(col_ptr), ip(row_ind),
+      ip(permute), fp(edge_max), fp(edge_sum), seed, offset, fp(in_feat), fp(attn_row), fp(attn_col), fp(grad),
+      fp(out_feat), fp(row_dot), fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb,
+      stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gat_backward_seeded");
+  return py::cast(std::vector<Tensor>{grad_feat, grad_attn_row, grad_attn_col});
+}
+
 // gat_backward with the per-row inputs packed: row_stat [m,h,4] = {attn_row, edge_max, edge_sum,
 // row_dot} (include/dgnn_hip.h, dgnn_gat_backward_packed).  -> [grad_feat, grad_attn_row,
 // grad_attn_col], or None where the packed entry point does not apply (caller unpacks).
@@ -670,6 +743,23 @@ PYBIND11_MODULE(fused_gatconv, m) {
       "grad_attn_row, grad_attn_col), entries may be None: write into these tensors instead of new ones.",
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("edge_max"), arg("edge_sum"), arg("edge_mask"), arg("in_feat"), arg("attn_row"),
+      arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
+      arg("out") = py::none());
+  def(m, "dropout_mask", &dropout_mask, "nnz, h, seed, offset, like",
+      "-> the [nnz,h] mask (on like's device) the *_seeded functions regenerate from (seed, offset)", arg("nnz"),
+      arg("h"), arg("seed"), arg("offset"), arg("like"));
+  def(m, "gat_forward_seeded", &gat_forward_seeded,
+      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, seed, offset=0, out=None",
+      "gat_forward with the dropout mask regenerated from (seed, offset): nothing is stored for the backward.\n"
+      "-> [out_feat, edge_max, edge_sum], or None where the seeded kernels do not apply.",
+      arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
+      arg("attn_drop"), arg("seed"), arg("offset") = 0, arg("out") = py::none());
+  def(m, "gat_backward_seeded", &gat_backward_seeded,
+      "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, seed, offset, "
+      "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",
+      "gat_backward with (seed, offset) in place of edge_mask.  -> [grad_feat, grad_attn_row, grad_attn_col] or None.",
+      arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
+      arg("permute"), arg("edge_max"), arg("edge_sum"), arg("seed"), arg("offset"), arg("in_feat"), arg("attn_row"),
       arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
       arg("out") = py::none());
   def(m, "gat_backward_packed", &gat_backward_packed,

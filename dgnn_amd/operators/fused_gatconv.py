@@ -5,6 +5,40 @@ from ..native import fused_gatconv as fused_gat
 from ._pad import pad4 as _pad4
 
 
+def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):
+    """-> (out_feat, edge_max, edge_sum, edge_mask or None, seed or None).  With attn_drop > 0 the
+    mask is not drawn and kept ([nnz,h] floats: 1 GB per layer at the products shape, what the
+    reference saves, fused_gatconv.py:18) but regenerated in the backward from a 62-bit seed taken
+    from torch's CPU generator (reproducible under torch.manual_seed, no device sync); shapes the
+    seeded kernels do not take get the SAME mask materialised."""
+    if not attn_drop > 0:
+        out, emax, esum, mask = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope,
+                                                      in_feat, attn_drop)
+        return out, emax, esum, mask, None
+    seed = int(torch.randint(0, 1 << 62, (1,)).item())
+    res = fused_gat.gat_forward_seeded(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, seed)
+    if res is not None:
+        return res[0], res[1], res[2], None, seed
+    mask = fused_gat.dropout_mask(col_ind.size(0), attn_row.size(1), seed, 0, in_feat)
+    out, emax, esum, mask = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat,
+                                                  attn_drop, edge_mask=mask)
+    return out, emax, esum, mask, None
+
+
+def _backward_with_dropout(ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask,
+                           in_feat, attn_row, attn_col, grad_out, out_feat):
+    if ctx.seed is not None:
+        res = fused_gat.gat_backward_seeded(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind,
+                                            permute, edge_max, edge_sum, ctx.seed, 0, in_feat, attn_row, attn_col,
+                                            grad_out, out_feat=out_feat)
+        if res is not None:
+            return res
+        edge_mask = fused_gat.dropout_mask(col_ind.size(0), attn_row.size(1), ctx.seed, 0, in_feat)
+    return fused_gat.gat_backward(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
+                                  edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad_out,
+                                  out_feat=out_feat)
+
+
 def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope,
                 in_feat, attn_drop):
     """dgNN/operators/fused_gatconv.py:6-7 (same argument order)."""
@@ -22,7 +56,8 @@ def GATConvFuse_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, 
 class FusedGATFunction(torch.autograd.Function):
     """dgNN/operators/fused_gatconv.py:12-34.  Differences, both invisible to callers: the
     forward output is saved too (it turns the backward's row term into one dense dot product,
-    removing a whole gather pass), and no [nnz,h] mask is kept when attn_drop == 0."""
+    removing a whole gather pass), and no [nnz,h] mask is kept: none exists at attn_drop == 0, and
+    at attn_drop > 0 the backward regenerates it from a seed (_forward_with_dropout)."""
 
     @staticmethod
     def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute,
@@ -31,7 +66,7 @@ class FusedGATFunction(torch.autograd.Function):
         attn_col = attn_col.contiguous()
         ctx.f = in_feat.size(2)
         in_feat = _pad4(in_feat.contiguous())          # odd widths run padded (see _pad4)
-        out_feat, edge_max, edge_sum, edge_mask = fused_gat.gat_forward(
+        out_feat, edge_max, edge_sum, edge_mask, ctx.seed = _forward_with_dropout(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
                               edge_mask, in_feat, attn_row, attn_col, out_feat)
@@ -44,9 +79,9 @@ class FusedGATFunction(torch.autograd.Function):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
          attn_row, attn_col, out_feat) = ctx.saved_tensors
         grad_out = _pad4(grad_out).contiguous()                # fused_gatconv.py:26
-        grad_feat, grad_attn_row, grad_attn_col = fused_gat.gat_backward(
-            ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
-            edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad_out, out_feat=out_feat)
+        grad_feat, grad_attn_row, grad_attn_col = _backward_with_dropout(
+            ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
+            attn_row, attn_col, grad_out, out_feat)
         if grad_feat.size(2) != ctx.f:
             grad_feat = grad_feat[..., :ctx.f]
         # same tuple layout as fused_gatconv.py:34
@@ -80,7 +115,7 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
         attn_row, attn_col = scores
         ctx.f = feat.size(2)
         feat_p = _pad4(feat)                              # odd widths run padded (see _pad4)
-        out_feat, edge_max, edge_sum, edge_mask = fused_gat.gat_forward(
+        out_feat, edge_max, edge_sum, edge_mask, ctx.seed = _forward_with_dropout(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, feat_p, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
                               edge_mask, feat, attn_row, attn_col, out_feat, attn_l, attn_r,
@@ -93,10 +128,9 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, feat,
          attn_row, attn_col, out_feat, attn_l, attn_r, feat_p) = ctx.saved_tensors
-        grad_feat, g_row, g_col = fused_gat.gat_backward(
-            ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
-            edge_max, edge_sum, edge_mask, feat if feat_p is None else feat_p, attn_row, attn_col,
-            _pad4(grad_out).contiguous(), out_feat=out_feat)
+        grad_feat, g_row, g_col = _backward_with_dropout(
+            ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask,
+            feat if feat_p is None else feat_p, attn_row, attn_col, _pad4(grad_out).contiguous(), out_feat)
         if grad_feat.size(2) != ctx.f:
             grad_feat = grad_feat[..., :ctx.f].contiguous()
         if ctx.fused_scores:

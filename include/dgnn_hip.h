@@ -145,6 +145,32 @@ int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative
                              float *grad_attn_row, float *grad_attn_col, void *workspace,
                              size_t workspace_bytes, void *stream);
 
+/* Dropout without a stored mask.  The reference draws edge_mask [nnz,h] ~ U(0,1] with cuRAND in
+ * every forward and keeps it for the backward (fused_gatconv_kernel.cu:333-341: nnz*h*4 bytes
+ * written, read three times, 1 GB per layer at the products shape).  The *_seeded entry points
+ * take (seed, offset) instead: element i of the virtual row-major [nnz,h] mask is component i % 4
+ * of Philox4x32-10 at counter (i / 4, offset) under key seed, mapped to (0,1]; the forward (by CSR
+ * position) and the backward (through permute) regenerate it.  Same arguments, outputs and
+ * workspace as dgnn_gat_forward / dgnn_gat_backward otherwise, and bit-identical results to those
+ * given the mask dgnn_dropout_mask materialises for the same (seed, offset).  DGNN_ERR_UNSUPPORTED
+ * where the neighbour-grouped kernels do not apply: materialise the mask and use the mask entry
+ * points (same values). */
+int dgnn_dropout_mask(int nnz, int h, uint64_t seed, uint64_t offset, float *mask, void *stream);
+int dgnn_gat_forward_seeded(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                            const float *attn_row, const float *attn_col, const int *row_ptr,
+                            const int *col_ind, const float *in_feat, uint64_t seed,
+                            uint64_t offset, float *edge_max, float *edge_sum, float *out_feat,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative_slope,
+                             float attn_drop, const int *row_ptr, const int *col_ind,
+                             const int *col_ptr, const int *row_ind, const int *permute,
+                             const float *edge_max, const float *edge_sum, uint64_t seed,
+                             uint64_t offset, const float *in_feat, const float *attn_row,
+                             const float *attn_col, const float *grad, const float *out_feat,
+                             const float *row_dot, float *grad_feat, float *grad_attn_row,
+                             float *grad_attn_col, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* ------------------------------------------------------- GE-SpMM / SDDMM / permute ---- */
 
 size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f);

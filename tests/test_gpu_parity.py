@@ -522,3 +522,77 @@ def test_spmm_autograd_operator(nat, h, f, pad_rows):
     assert_close(host(out), ref.detach().numpy(), "spmm out", atol=1e-5)
     assert_close(host(x.grad), X.grad.numpy(), "spmm grad feat", atol=1e-5)
     assert_close(host(v.grad), V.grad.numpy(), "spmm grad val", atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- dropout without a stored mask
+def test_dropout_mask_is_a_pure_function_of_seed_and_offset(nat):
+    x = torch.zeros(1, device=DEV)
+    a = nat["gat"].dropout_mask(100003, 3, 12345, 0, x)
+    assert a.shape == (100003, 3) and a.dtype == torch.float32
+    assert torch.equal(a, nat["gat"].dropout_mask(100003, 3, 12345, 0, x))
+    assert not torch.equal(a, nat["gat"].dropout_mask(100003, 3, 12346, 0, x))
+    assert not torch.equal(a, nat["gat"].dropout_mask(100003, 3, 12345, 1, x))
+    # a prefix of a longer mask of the same seed: element i depends on i only
+    assert torch.equal(a.flatten()[:50001], nat["gat"].dropout_mask(16667, 3, 12345, 0, x).flatten())
+    v = host(a).astype(np.float64)
+    assert v.min() > 0.0 and v.max() <= 1.0                      # (0, 1] like the reference's cuRAND floats
+    assert abs(v.mean() - 0.5) < 5e-3 and abs((v > 0.3).mean() - 0.7) < 5e-3
+    assert abs(np.corrcoef(v[:-1, 0], v[1:, 0])[0, 1]) < 0.02
+
+
+@pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 64), (2, 16), (8, 32), (3, 6), (5, 33)])
+def test_gat_seeded_dropout_equals_the_materialised_mask(nat, name, h, f):
+    """gat_forward_seeded / gat_backward_seeded regenerate the mask from (seed, offset): the same
+    bits as the mask entry points (held to the oracle above) given dropout_mask(seed, offset)."""
+    g = GRAPHS[name]
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=17)
+    G = gdev(g)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    seed, p = 0x1234_5678_9ABC_DEF, 0.4
+    mask = nat["gat"].dropout_mask(g["nnz"], h, seed, 0, x)
+    ref = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, edge_mask=mask)
+    got = nat["gat"].gat_forward_seeded(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, seed)
+    assert got is not None and all(torch.equal(a, b) for a, b in zip(got, ref[:3]))
+    bref = nat["gat"].gat_backward(0.2, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                   ref[1], ref[2], mask, x, ar, ac, go, out_feat=ref[0])
+    bgot = nat["gat"].gat_backward_seeded(0.2, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                          ref[1], ref[2], seed, 0, x, ar, ac, go, out_feat=ref[0])
+    assert bgot is not None and all(torch.equal(a, b) for a, b in zip(bgot, bref))
+    # the dropped share is about p, and another seed drops other edges
+    kept = float((mask > p).float().mean())
+    assert abs(kept - (1 - p)) < 0.05
+    other = nat["gat"].gat_forward_seeded(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, seed + 1)
+    assert not torch.equal(other[0], got[0])
+
+
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 47), (9, 8)])
+def test_gat_operator_dropout_keeps_no_mask_and_matches_the_oracle(nat, h, f, pad_rows):
+    """GATConvFuse with attn_drop > 0: the seed comes from torch's CPU generator (reproducible);
+    where the seeded kernels apply no [nnz,h] tensor exists at all (nine heads: the SAME mask
+    materialised); values and gradients equal the oracle's for that very mask."""
+    from dgnn_amd.operators import GATConvFuse
+    g = GRAPHS["powerlaw256"]
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=23)
+    G = gdev(g)
+    p = 0.5
+
+    def run():
+        torch.manual_seed(99)
+        x, ar, ac = (dev(t).requires_grad_() for t in (in_feat, attn_row, attn_col))
+        out = GATConvFuse(ar, ac, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], 0.2, x, p)
+        out.backward(dev(grad))
+        return out.detach(), x.grad, ar.grad, ac.grad
+
+    a, b = run(), run()
+    assert all(torch.equal(u, v) for u, v in zip(a, b)), "same torch seed, same result"
+    torch.manual_seed(99)
+    seed = int(torch.randint(0, 1 << 62, (1,)).item())
+    mask = host(nat["gat"].dropout_mask(g["nnz"], h, seed, 0, a[0]))
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, p, mask)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, p, g["row_ptr"], g["col_ind"], mask, in_feat, attn_row, attn_col, grad)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2, p)
+    assert_close(host(a[0]), o64, "dropout out_feat", mass=m_out)
+    assert_close(host(a[1]), gf64, "dropout grad_feat", mass=m_gf)
+    assert_close(host(a[2]), gr64, "dropout grad_attn_row", mass=m_gr)
+    assert_close(host(a[3]), gc64, "dropout grad_attn_col", mass=m_gc)
