@@ -31,6 +31,7 @@ namespace dgnn {
 
 struct BwdParams {
   int n, m, nnz, H, F, HF, L, T;
+  int steady;          // narrow rows: unguarded steady-state gather stream (STEADY instantiation)
   int vec;             // floats per lane load: 4 (F % 4 == 0, 16-byte aligned rows) or 1
   int fv;              // lanes per head: power of two >= ceil(F/vec), <= 64
   int hpp;             // heads per lane pass = 64 / fv; ceil(H / hpp) passes walk the stream
@@ -152,7 +153,9 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
 // GMMConv backward (replaces mhsddmm + mhtranspose + gmmconv on the CSC,
 // dgNN/operators/fused_gmmconv.py:21-24): grad_node_feat[c,k,:] = sum_i w_ik grad[r_i,k,:] with
 // w_ik = Gaussian weight of edge i, and grad_gauss[permute[i],k] = <grad[r_i,k,:], node_feat[c,k,:]>.
-template <int HC, int EPL, int VEC, int BMODE>
+// STEADY: instantiation for narrow rows (fewer than 64 float4 slots), bound by instructions per
+// edge: adds an unguarded steady-state form of the gather stream (see gather_fast.hpp).
+template <int HC, int EPL, int VEC, int BMODE, bool STEADY>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   using V = VecT<VEC>;
   using vec_t = typename V::type;
@@ -287,6 +290,80 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     float dsum = 0.f;
     int k = -1;
     vec_t ring[DGNN_FAST_U];
+    bool took_steady = false;
+    if constexpr (STEADY) {
+      if (P.steady && items >= 2 * DGNN_FAST_U) {
+        took_steady = true;
+        // one item of the stream, its row already in x
+        auto consume = [&](const vec_t &x, unsigned v, int it) {
+          if (v & DGNN_BWD_UFLAG) {
+            u = x;
+            ++k;
+          } else {
+            const int p = it - (k + 1);
+            float2 *cp = cell + (size_t)p * HC + head;
+            const float2 wb = *cp;
+            const float w = fabsf(wb.x);
+            const float sl = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
+            float dot = active ? vec_dot<VEC>(x, u) : 0.f;
+            dot = group_reduce(dot, P.fv, OpSum());
+            const float d = (BMODE == BWD_GMM) ? dot : fmaf(sl * w, dot, -wb.y);
+            V::fma(acc, w, x);
+            dsum += d;
+            if (head_leader) cp->y = d;
+            if (v & DGNN_BWD_END) {
+              const int dst = uniform_i32(dq[k]);
+              if (dst >= 0) {
+                if (active) *(vec_t *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
+                if (BMODE == BWD_GAT && head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
+              } else {
+                float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
+                if (active) *(vec_t *)(sp + lane_off) = acc;
+                if (BMODE == BWD_GAT && head_leader) sp[P.HF + head] = dsum;
+              }
+              acc = V::zero();
+              dsum = 0.f;
+            }
+          }
+        };
+        auto row_of = [&](unsigned v) -> const float * {
+          return ((v & DGNN_BWD_UFLAG) ? P.in_feat : P.grad) + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off;
+        };
+        // unguarded fill and loop: loads issued unconditionally (idle lanes re-read slot 0 of the
+        // row), a slot consumed before it is refilled
+#pragma unroll
+        for (int i = 0; i < DGNN_FAST_U; ++i) {
+          ring[i] = *(const vec_t *)row_of((unsigned)uniform_i32((int)stream[i]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        int j = 0;
+        for (; j + 2 * DGNN_FAST_U <= items; j += DGNN_FAST_U) {
+#pragma unroll
+          for (int i = 0; i < DGNN_FAST_U; ++i) {
+            const int it = j + i;
+            const unsigned v = (unsigned)uniform_i32((int)stream[it]);
+            const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
+            consume(ring[i], v, it);
+            ring[i] = *(const vec_t *)row_of(nv);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        for (; j < items; j += DGNN_FAST_U) {
+#pragma unroll
+          for (int i = 0; i < DGNN_FAST_U; ++i) {
+            const int it = j + i;
+            if (it < items) {
+              const vec_t x = ring[i];
+              const unsigned v = (unsigned)uniform_i32((int)stream[it]);
+              if (it + DGNN_FAST_U < items)
+                ring[i] = *(const vec_t *)row_of((unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]));
+              consume(x, v, it);
+            }
+          }
+        }
+      }
+    }
+    if (!took_steady) {
   #pragma unroll
     for (int i = 0; i < DGNN_FAST_U; ++i) {
       ring[i] = V::zero();
@@ -339,6 +416,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           }
         }
       }
+    }
     }
   }
   wave_lds_sync();

@@ -85,6 +85,9 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   const bool attn_ok = (MODE != MODE_GAT) || P.H != 4 || aligned16(P.attn_col);
   if (!attn_ok) return DGNN_ERR_ALIGNMENT;
   P.rowv = vec4 ? P.HF / 4 : P.HF;
+  // rows narrower than one wave of float4 slots are bound by instructions per edge, not bandwidth
+  // (the STEADY instantiation of the kernel; DGNN_FWD_STEADY=0 switches it off for A/B runs)
+  P.steady = (vec4 && P.rowv < DGNN_WAVE && env_int("DGNN_FWD_STEADY", 1) != 0) ? 1 : 0;
   {
     long long g = ((long long)P.m + 255) / 256;
     if (g > 8192) g = 8192;
@@ -98,17 +101,19 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   if (MODE == MODE_GAT) timer_mark(0, 0, st);
   // vector slots per lane: one walk over the edges for rows up to 64 / 128 / 256 slots
   const int ns = P.rowv <= DGNN_WAVE ? 1 : P.rowv <= 2 * DGNN_WAVE ? 2 : 4;
+  const bool steady = P.steady != 0;
   // all-heads-at-once softmax phase for 1 / 2 / 8 heads (per-head vectors need aligned tensors)
   int ht = 0;
   if (MODE == MODE_GAT && (P.H == 1 || P.H == 2 || P.H == 8) && aligned16(P.attn_row) &&
       aligned16(P.attn_col) && aligned16(P.edge_mask) && aligned16(P.edge_max) && aligned16(P.edge_sum))
     ht = P.H;
-#define DGNN_FWD_CASE(VECV, NSV, HTV)                                                          \
-  if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV)                                        \
-    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV>), grid, dim3(DGNN_BLOCK), lds, st, P);
+#define DGNN_FWD_CASE(VECV, NSV, HTV, STV)                                                     \
+  if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV && steady == STV)                       \
+    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV, STV>), grid, dim3(DGNN_BLOCK), lds, st, P);
 #define DGNN_FWD_CASES(HTV)                                                                    \
-  DGNN_FWD_CASE(4, 1, HTV) DGNN_FWD_CASE(4, 2, HTV) DGNN_FWD_CASE(4, 4, HTV)                   \
-  DGNN_FWD_CASE(1, 1, HTV) DGNN_FWD_CASE(1, 2, HTV) DGNN_FWD_CASE(1, 4, HTV)
+  DGNN_FWD_CASE(4, 1, HTV, true)                                                               \
+  DGNN_FWD_CASE(4, 1, HTV, false) DGNN_FWD_CASE(4, 2, HTV, false) DGNN_FWD_CASE(4, 4, HTV, false) \
+  DGNN_FWD_CASE(1, 1, HTV, false) DGNN_FWD_CASE(1, 2, HTV, false) DGNN_FWD_CASE(1, 4, HTV, false)
   DGNN_FWD_CASES(0)
   if (MODE == MODE_GAT) {
     DGNN_FWD_CASES(1) DGNN_FWD_CASES(2) DGNN_FWD_CASES(8)
@@ -219,10 +224,12 @@ void launch_bwd_gather(const BwdParams &P, int hc, int vec, dim3 grid, dim3 bloc
                        hipStream_t st) {
 #define DGNN_BWD_CASE(HC, EPL)                                                                    \
   if (hc == HC && P.L == 64 * EPL) {                                                              \
-    if (vec == 4)                                                                                 \
-      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4, BMODE>), grid, block, lds, st, P);         \
+    if (vec == 4 && P.steady)                                                                     \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4, BMODE, true>), grid, block, lds, st, P);   \
+    else if (vec == 4)                                                                            \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4, BMODE, false>), grid, block, lds, st, P);  \
     else                                                                                          \
-      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 1, BMODE>), grid, block, lds, st, P);         \
+      hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 1, BMODE, false>), grid, block, lds, st, P);  \
   }
   DGNN_BWD_CASE(1, 1) DGNN_BWD_CASE(1, 2) DGNN_BWD_CASE(1, 4)
   DGNN_BWD_CASE(2, 1) DGNN_BWD_CASE(2, 2) DGNN_BWD_CASE(2, 4)
@@ -374,6 +381,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
     P.L = w.L; P.T = w.T; P.vec = vec; P.fv = bwd_lanes_per_head(f, vec); P.slot_stride = w.slot_stride;
     P.hpp = DGNN_WAVE / P.fv;
+    P.steady = (vec == 4 && h * f / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
     const int hc = bwd_heads_padded(h);
     P.attn_drop = attn_drop; P.slope = negative_slope;
     P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
@@ -611,6 +619,7 @@ int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const
   P.L = bwd_group_size(hc, nnz);
   P.T = (nnz + P.L - 1) / P.L;
   P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
+  P.steady = (vec == 4 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
   P.slot_stride = (int)align_up((size_t)kernels * embed + kernels, 4);
   P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
   P.in_feat = node_feat; P.grad = grad; P.grad_feat = grad_node_feat; P.grad_attn_col = nullptr;

@@ -43,6 +43,7 @@ struct GatherParams {
   int rowv;                          // HF / VEC : vector slots per feature row
   int slot_stride;                   // floats per partial slot (HF + 2H rounded up to 4)
   int dim;                           // GMM pseudo dimension
+  int steady;                        // narrow rows: unguarded steady-state gather loop (phase C)
   float attn_drop, slope;
   const int *row_ptr, *col_ind;
   const float *attn_row, *attn_col;  // GAT
@@ -160,7 +161,10 @@ __device__ __forceinline__ void st_heads(float *p, const float (&d)[HT]) {
 
 // HT = compile-time head count of the all-heads-at-once softmax phase for 1, 2 or 8 heads
 // (0: run-time H; H == 4 keeps its own float4 path below).
-template <int MODE, int VEC, int NS, int HT>
+// STEADY: the instantiation for narrow rows (fewer than 64 float4 slots), whose gather loop is
+// bound by instructions per edge: it adds an unguarded steady-state loop (phase C).  Wide rows
+// keep the kernel without it (the extra path costs the 4 x 64 kernel 10 % through registers).
+template <int MODE, int VEC, int NS, int HT, bool STEADY>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) {
   constexpr int HTA = HT > 0 ? HT : 1;     // array extent that is legal for HT == 0 too
   using V = VecT<VEC>;
@@ -413,58 +417,144 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       acc[s] = V::zero();
     }
     int q = 0;
+    bool took_steady = false;
+    if constexpr (STEADY) {
+    // One edge of the stream: accumulate (w, x) and flush at a row end.
+    auto consume = [&](const vec_t (&x)[NS], const float (&w)[NS], unsigned ci) {
 #pragma unroll
-    for (int k = 0; k < DGNN_FAST_U; ++k) {
+      for (int s = 0; s < NS; ++s) V::fma(acc[s], w[s], x[s]);
+      if (ci & DGNN_ROWEND) {
+        const int d = uniform_i32(dq[q]);
+        ++q;
+        float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
+          acc[s] = V::zero();
+        }
+      }
+    };
+    // Guarded step of the pipeline (pipeline fill, tails, dropout): loads sit under conditions.
+    auto guarded_step = [&](int p, vec_t (&slot)[NS], float (&wslot)[NS]) {
+      vec_t x[NS];
+      float w[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        ring[k][s] = V::zero();
-        wring[k][s] = 0.f;
+        x[s] = slot[s];
+        w[s] = wslot[s];
       }
-      if (k < cnt) {
+      const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
+      if (p + DGNN_FAST_U < cnt) {
+        const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          wslot[s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
+          if (active[s] && !(skip0 && wslot[s] == 0.f))
+            slot[s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+          else
+            slot[s] = V::zero();
+        }
+      }
+      consume(x, w, ci);
+    };
+    if (P.steady && !skip0 && cnt >= 2 * DGNN_FAST_U) {
+      took_steady = true;
+      // Steady path for NARROW rows (every full group without dropout), where the loop is bound
+      // by its instruction count, not by bandwidth: fill and loop body issue their gathers
+      // unconditionally (idle lanes re-read slot 0 of the row) and a slot is consumed before it is
+      // refilled, which removes the guards and the register copies of the refilled slots (and
+      // lets the compiler count the loads in flight instead of draining them before every use).
+#pragma unroll
+      for (int k = 0; k < DGNN_FAST_U; ++k) {
         const unsigned c = uniform_i32((int)(cidx[k] & ~DGNN_ROWEND));
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           wring[k][s] = wbase[s][(size_t)k * H];
-          if (active[s] && !(skip0 && wring[k][s] == 0.f))
-            ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+          ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
         }
+        __builtin_amdgcn_sched_barrier(0);   // issue order = slot order (the waits count loads)
       }
-    }
-    for (int j = 0; j < cnt; j += DGNN_FAST_U) {
+      int j = 0;
+      for (; j + 2 * DGNN_FAST_U <= cnt; j += DGNN_FAST_U) {
 #pragma unroll
-      for (int k = 0; k < DGNN_FAST_U; ++k) {
-        const int p = j + k;
-        if (p < cnt) {
-          vec_t x[NS];
-          float w[NS];
+        for (int k = 0; k < DGNN_FAST_U; ++k) {
+          const int p = j + k;
+          const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
+          const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
+          float wnext[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) wnext[s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
+          consume(ring[k], wring[k], ci);
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
-            x[s] = ring[k][s];
-            w[s] = wring[k][s];
+            wring[k][s] = wnext[s];
+            ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
           }
-          const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
-          if (p + DGNN_FAST_U < cnt) {
-            const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      for (; j < cnt; j += DGNN_FAST_U) {
+#pragma unroll
+        for (int k = 0; k < DGNN_FAST_U; ++k)
+          if (j + k < cnt) guarded_step(j + k, ring[k], wring[k]);
+      }
+    }
+    }
+    if (!took_steady) {
+      // Guarded pipeline exactly as tuned for wide rows (bandwidth-bound: 4 x 64 and up).
+#pragma unroll
+      for (int k = 0; k < DGNN_FAST_U; ++k) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          ring[k][s] = V::zero();
+          wring[k][s] = 0.f;
+        }
+        if (k < cnt) {
+          const unsigned c = uniform_i32((int)(cidx[k] & ~DGNN_ROWEND));
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            wring[k][s] = wbase[s][(size_t)k * H];
+            if (active[s] && !(skip0 && wring[k][s] == 0.f))
+              ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+          }
+        }
+      }
+      for (int j = 0; j < cnt; j += DGNN_FAST_U) {
+#pragma unroll
+        for (int k = 0; k < DGNN_FAST_U; ++k) {
+          const int p = j + k;
+          if (p < cnt) {
+            vec_t x[NS];
+            float w[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-              wring[k][s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
-              if (active[s] && !(skip0 && wring[k][s] == 0.f))
-                ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
-              else
-                ring[k][s] = V::zero();
+              x[s] = ring[k][s];
+              w[s] = wring[k][s];
             }
-          }
+            const unsigned ci = (unsigned)uniform_i32((int)cidx[p]);
+            if (p + DGNN_FAST_U < cnt) {
+              const unsigned c = (unsigned)uniform_i32((int)(cidx[p + DGNN_FAST_U] & ~DGNN_ROWEND));
 #pragma unroll
-          for (int s = 0; s < NS; ++s) V::fma(acc[s], w[s], x[s]);
-          if (ci & DGNN_ROWEND) {
-            const int d = uniform_i32(dq[q]);
-            ++q;
-            float *dst = (d >= 0) ? P.out + (size_t)d * P.HF
-                                  : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+              for (int s = 0; s < NS; ++s) {
+                wring[k][s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
+                if (active[s] && !(skip0 && wring[k][s] == 0.f))
+                  ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+                else
+                  ring[k][s] = V::zero();
+              }
+            }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-              if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
-              acc[s] = V::zero();
+            for (int s = 0; s < NS; ++s) V::fma(acc[s], w[s], x[s]);
+            if (ci & DGNN_ROWEND) {
+              const int d = uniform_i32(dq[q]);
+              ++q;
+              float *dst = (d >= 0) ? P.out + (size_t)d * P.HF
+                                    : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+#pragma unroll
+              for (int s = 0; s < NS; ++s) {
+                if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
+                acc[s] = V::zero();
+              }
             }
           }
         }
