@@ -330,7 +330,8 @@ def main():
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
                                    f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd",
                        "parallelism": "single GPU" if world == 1 else
-                       f"row-partition x{world}, RCCL {os.environ.get('DGNN_DIST_MODE', 'halo')} exchange of boundary rows"},
+                       f"row-partition x{world}, RCCL {os.environ.get('DGNN_DIST_MODE', 'halo')} exchange of boundary rows"
+                       + (f", {runner.chunks} pipelined chunks" if runner.mode == "halo" else "")},
         }
         if roof is not None:
             line["roofline"] = roof
