@@ -55,8 +55,9 @@ struct BwdParams {
 
 enum { BWD_GAT = 0, BWD_GMM = 1 };
 
-static inline int bwd_group_size(int H, int nnz) {
-  const int dflt = H <= 4 ? 256 : 128;
+static inline int bwd_group_size(int H, int nnz, bool narrow = false) {
+  // narrow rows: see narrow_rows() in gather_fast.hpp (4 x 16 backward 9.4 -> 7.2 ms with 128)
+  const int dflt = narrow ? (H <= 4 ? 128 : 64) : (H <= 4 ? 256 : 128);
   const int v = env_int("DGNN_BWD_L", 0);      // tuning override: 64, 128 or 256
   if (!(v == 64 || v == 128 || v == 256)) return shrink_group_for_small_graphs(dflt, nnz, 64);
   return (H > 4 && v > 128) ? 128 : v;

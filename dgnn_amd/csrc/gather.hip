@@ -57,7 +57,7 @@ struct FwdLayout {
 
 FwdLayout fwd_layout(int nnz, int h, int f) {
   FwdLayout w;
-  w.L = fast_group_size(h, nnz);
+  w.L = fast_group_size(h, nnz, narrow_rows(h, f));
   w.T = (nnz + w.L - 1) / w.L;
   w.slot_stride = (int)align_up((size_t)h * f + 2 * (size_t)h, 4);
   size_t o = 0;
@@ -200,7 +200,7 @@ BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
   w.off_long = o;                                // [0] = counter, [1..] = queue
   o += align_up(sizeof(int) * ((size_t)w.max_long + 1), 256);
   if (w.fast) {
-    w.L = bwd_group_size(bwd_heads_padded(h), nnz);
+    w.L = bwd_group_size(bwd_heads_padded(h), nnz, narrow_rows(h, f));
     w.T = (nnz + w.L - 1) / w.L;
     w.slot_stride = (int)align_up((size_t)h * f + (size_t)h, 4);
     w.off_stat = o;
@@ -588,7 +588,7 @@ static bool gmm_backward_fused_shape(int nodes, int kernels, int embed) {
 size_t dgnn_gmm_backward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
   if (nodes < 0 || nnz < 0 || kernels <= 0 || embed <= 0) return 0;
   if (!gmm_backward_fused_shape(nodes, kernels, embed)) return 0;
-  const int L = bwd_group_size(bwd_heads_padded(kernels), nnz);
+  const int L = bwd_group_size(bwd_heads_padded(kernels), nnz, narrow_rows(kernels, embed));
   const size_t T = ((size_t)nnz + L - 1) / L;
   const size_t stride = align_up((size_t)kernels * embed + kernels, 4);
   return align_up(sizeof(int) * (T > 0 ? T : 1), 256) + align_up(sizeof(float) * 2 * T * stride, 256);
@@ -616,7 +616,7 @@ int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const
   BwdParams P = {};
   P.n = nodes; P.m = nodes; P.nnz = nnz; P.H = kernels; P.F = embed; P.HF = kernels * embed;
   const int hc = bwd_heads_padded(kernels);
-  P.L = bwd_group_size(hc, nnz);
+  P.L = bwd_group_size(hc, nnz, narrow_rows(kernels, embed));
   P.T = (nnz + P.L - 1) / P.L;
   P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
   P.steady = (vec == 4 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
