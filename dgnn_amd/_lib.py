@@ -51,6 +51,8 @@ SIGNATURES = {
     "dgnn_gaussian_backward": (_i, [_i, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),
     "dgnn_edgeconv_forward": (_i, [_i, _i, _i] + [_vp] * 6 + [_vp]),
     "dgnn_edgeconv_backward": (_i, [_i, _i] + [_vp] * 3 + [_vp]),
+    "dgnn_edgeconv_backward_det_workspace_bytes": (_sz, [_i, _i]),
+    "dgnn_edgeconv_backward_det": (_i, [_i, _i, _i] + [_vp] * 4 + [_vp, _sz, _vp]),
     "dgnn_csr2csc_workspace_bytes": (_sz, [_i, _i, _i]),
     "dgnn_csr2csc": (_i, [_i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_coo2csr": (_i, [_i, _i] + [_vp] * 2 + [_vp]),

@@ -358,6 +358,50 @@ static inline int grid_1d(long long total, int block) {
 
 }  // namespace dgnn
 
+// ---- deterministic EdgeConv backward: a gather over the REVERSED k-NN lists -----------------
+// grad_src[s,c] = sum over the points r that list s among their neighbours, ascending r, of
+// grad_out[r,c] where max_idx[r,c] == s.  Same values as the scatter of k_edgeconv_bwd, summed in
+// a fixed order and without float atomics (whose 64 lanes land in up to k different rows).
+__global__ void k_fill_list_ptr(int m, int k, int *__restrict__ ptr) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i <= m; i += (long long)gridDim.x * blockDim.x)
+    ptr[i] = (int)(i * k);
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void k_edgeconv_bwd_gather(long long total, int slots, int F,
+                                                             const int *__restrict__ col_ptr,
+                                                             const int *__restrict__ row_ind,
+                                                             const int *__restrict__ max_idx,
+                                                             const float *__restrict__ grad_out,
+                                                             float *__restrict__ grad_src) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+  const int s = (int)(t / slots), q = (int)(t - (long long)s * slots);
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  int prev = -1;
+  for (int e = col_ptr[s]; e < col_ptr[s + 1]; ++e) {
+    const int r = row_ind[e];
+    if (r == prev) continue;                 // s listed twice by r: one contribution, as the scatter
+    prev = r;
+    const size_t at = (size_t)r * F + (size_t)q * VEC;
+    if (VEC == 4) {
+      const int4 id = *(const int4 *)(max_idx + at);
+      const float4 g = *(const float4 *)(grad_out + at);
+      acc[0] += id.x == s ? g.x : 0.f; acc[1 % VEC] += id.y == s ? g.y : 0.f;
+      acc[2 % VEC] += id.z == s ? g.z : 0.f; acc[3 % VEC] += id.w == s ? g.w : 0.f;
+    } else {
+      acc[0] += max_idx[at] == s ? grad_out[at] : 0.f;
+    }
+  }
+  const size_t o = (size_t)s * F + (size_t)q * VEC;
+  if (VEC == 4)
+    *(float4 *)(grad_src + o) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+  else
+    grad_src[o] = acc[0];
+  }
+}
+
 extern "C" {
 
 int dgnn_abi_version(void) { return 1; }
@@ -488,6 +532,48 @@ int dgnn_edgeconv_backward(int m, int f, const int *max_idx, const float *grad_o
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_edgeconv_bwd, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, f, max_idx,
                      grad_out, grad_src);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+static size_t edgeconv_det_align(size_t x) { return (x + 255) / 256 * 256; }
+
+size_t dgnn_edgeconv_backward_det_workspace_bytes(int m, int k) {
+  if (m < 0 || k < 0 || (long long)m * k > 0x7fffffffLL) return 0;
+  const size_t nnz = (size_t)m * k;
+  return 2 * edgeconv_det_align(sizeof(int) * ((size_t)m + 1)) + 2 * edgeconv_det_align(sizeof(int) * (nnz > 0 ? nnz : 1)) +
+         edgeconv_det_align(dgnn_csr2csc_workspace_bytes(m, m, (int)nnz));
+}
+
+int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const int *max_idx,
+                               const float *grad_out, float *grad_src, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+  if (m < 0 || f <= 0 || k < 0 || (long long)m * k > 0x7fffffffLL) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (!max_idx || !grad_out || !grad_src || (k > 0 && !src_ind)) return DGNN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < dgnn_edgeconv_backward_det_workspace_bytes(m, k)) return DGNN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nnz = m * k;
+  char *w = (char *)workspace;
+  int *list_ptr = (int *)w;               w += edgeconv_det_align(sizeof(int) * ((size_t)m + 1));
+  int *col_ptr = (int *)w;                w += edgeconv_det_align(sizeof(int) * ((size_t)m + 1));
+  int *row_ind = (int *)w;                w += edgeconv_det_align(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  int *perm = (int *)w;                   w += edgeconv_det_align(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  const size_t sort_bytes = dgnn_csr2csc_workspace_bytes(m, m, nnz);
+  hipLaunchKernelGGL(k_fill_list_ptr, dim3(grid_1d((long long)m + 1, 256)), dim3(256), 0, st, m, k, list_ptr);
+  DGNN_LAUNCH_CHECK();
+  // the k-NN lists are the CSR of an m x m matrix (row = point, columns = its neighbours)
+  int rc = dgnn_csr2csc(m, m, nnz, list_ptr, src_ind, col_ptr, row_ind, perm, w, sort_bytes, stream);
+  if (rc) return rc;
+  const bool vec4 = (f % 4 == 0) && ((((uintptr_t)max_idx | (uintptr_t)grad_out | (uintptr_t)grad_src) & 15u) == 0);
+  const int slots = vec4 ? f / 4 : f;
+  const long long total = (long long)m * slots;
+  if (vec4)
+    hipLaunchKernelGGL(k_edgeconv_bwd_gather<4>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
+                       col_ptr, row_ind, max_idx, grad_out, grad_src);
+  else
+    hipLaunchKernelGGL(k_edgeconv_bwd_gather<1>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
+                       col_ptr, row_ind, max_idx, grad_out, grad_src);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

@@ -541,13 +541,26 @@ std::vector<Tensor> edgeconv_forward(int64_t k, const Tensor &src_ind, const Ten
   return {out, idx_f};
 }
 
-// -> grad_src   (fused_edgeconv.cpp:32-45); max_idx int32
-Tensor edgeconv_backward(const Tensor &grad_out, const Tensor &max_idx) {
+// -> grad_src   (fused_edgeconv.cpp:32-45); max_idx int32.  src_ind (keyword, not in the reference
+// signature): the k-NN lists the forward was given -- with them the gradient is gathered over the
+// transposed lists in a fixed order, without float atomics (dgnn_edgeconv_backward_det).
+Tensor edgeconv_backward(const Tensor &grad_out, const Tensor &max_idx, const OptTensor &src_ind) {
   f32(grad_out, "grad_out", 2), i32(max_idx, "max_idx", 2);
   if (max_idx.sizes() != grad_out.sizes()) fail("edgeconv_backward: max_idx and grad_out must both be [m,f]");
   const int m = as_int(grad_out.size(0), "points"), f = as_int(grad_out.size(1), "features");
   c10::DeviceGuard guard(grad_out.device());
   Tensor grad_src = new_f32({m, f}, grad_out);
+  if (given(src_ind) && m > 0) {
+    i32(*src_ind, "src_ind");
+    if (src_ind->numel() % m != 0) fail("edgeconv_backward: src_ind must hold m*k ids");
+    const int k = as_int(src_ind->numel() / m, "k");
+    const size_t nb = API(dgnn_edgeconv_backward_det_workspace_bytes)(m, k);
+    Tensor ws = workspace(nb, grad_out);
+    check_rc(API(dgnn_edgeconv_backward_det)(m, f, k, ip(*src_ind), ip(max_idx), fp(grad_out), fo(grad_src),
+                                             ptr<void>(ws), nb, stream_of(grad_out)),
+             "dgnn_edgeconv_backward_det");
+    return grad_src;
+  }
   check_rc(API(dgnn_edgeconv_backward)(m, f, ip(max_idx), fp(grad_out), fo(grad_src), stream_of(grad_out)),
            "dgnn_edgeconv_backward");
   return grad_src;
@@ -797,8 +810,10 @@ PYBIND11_MODULE(fused_edgeconv, m) {
   def(m, "edgeconv_forward", &edgeconv_forward, "k, src_ind, h_src, h_dst, return_int_idx=False",
       "-> [out_feat, max_idx(float32)] (+ the exact int32 ids with return_int_idx)   (fused_edgeconv.cpp:11-27)",
       arg("k"), arg("src_ind"), arg("h_src"), arg("h_dst"), arg("return_int_idx") = false);
-  def(m, "edgeconv_backward", &edgeconv_backward, "grad_out, max_idx", "-> grad_src   (fused_edgeconv.cpp:32-45)",
-      arg("grad_out"), arg("max_idx"));
+  def(m, "edgeconv_backward", &edgeconv_backward, "grad_out, max_idx, src_ind=None",
+      "-> grad_src   (fused_edgeconv.cpp:32-45).  With src_ind (the forward's k-NN lists): fixed summation\n"
+      "order, no float atomics.",
+      arg("grad_out"), arg("max_idx"), arg("src_ind") = py::none());
 }
 
 PYBIND11_MODULE(mhsddmm, m) {

@@ -17,12 +17,13 @@ class FusedEdgeConvFunction(torch.autograd.Function):
     def forward(ctx, k, src_ind, h_src, h_dst):
         out_feat, _max_idx_f, max_idx = fused_edgeconv.edgeconv_forward(
             k, src_ind, h_src.contiguous(), h_dst.contiguous(), return_int_idx=True)
-        ctx.save_for_backward(max_idx)
+        ctx.save_for_backward(max_idx, src_ind)
         return out_feat
 
     @staticmethod
     def backward(ctx, grad_out):
-        max_idx = ctx.saved_tensors[0]
+        max_idx, src_ind = ctx.saved_tensors
         grad_out = grad_out.contiguous()
-        grad_src = fused_edgeconv.edgeconv_backward(grad_out, max_idx)
+        # gathered over the transposed k-NN lists: fixed summation order, no float atomics
+        grad_src = fused_edgeconv.edgeconv_backward(grad_out, max_idx, src_ind=src_ind)
         return None, None, grad_src, grad_out                  # grad_h_dst is grad_out itself, :22

@@ -238,6 +238,16 @@ int dgnn_edgeconv_forward(int m, int f, int k, const int *src_ind, const float *
 int dgnn_edgeconv_backward(int m, int f, const int *max_idx, const float *grad_out,
                            float *grad_src, void *stream);
 
+/* The same gradient WITHOUT float atomics, summed in a fixed order (run-to-run identical bits):
+ * the k-NN lists src_ind [m*k] are transposed on the device (dgnn_csr2csc) and every source s
+ * gathers, over the points r that list it in ascending r, grad_out[r,c] where max_idx[r,c] == s.
+ * Needs the lists the forward was given (ids in [0, m)); the reference's backward signature
+ * (fused_edgeconv.cpp:32-45) carries only grad_out and max_idx, hence a separate entry point. */
+size_t dgnn_edgeconv_backward_det_workspace_bytes(int m, int k);
+int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const int *max_idx,
+                               const float *grad_out, float *grad_src, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* -------------------------------------------------------------------- index work ---- */
 
 size_t dgnn_csr2csc_workspace_bytes(int m, int n, int nnz);

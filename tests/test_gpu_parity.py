@@ -596,3 +596,26 @@ def test_gat_operator_dropout_keeps_no_mask_and_matches_the_oracle(nat, h, f, pa
     assert_close(host(a[1]), gf64, "dropout grad_feat", mass=m_gf)
     assert_close(host(a[2]), gr64, "dropout grad_attn_row", mass=m_gr)
     assert_close(host(a[3]), gc64, "dropout grad_attn_col", mass=m_gc)
+
+
+@pytest.mark.parametrize("m,k,f", [(300, 7, 5), (4096, 20, 64), (2000, 40, 130), (40000, 20, 256), (50, 1, 8)])
+def test_edgeconv_backward_gathered_is_deterministic_and_exact(nat, m, k, f):
+    """edgeconv_backward with src_ind: gathered over the transposed k-NN lists in ascending r, so
+    the float32 result equals a sequential float32 scatter in row-major order bit for bit (and the
+    atomic scatter within tolerance); a neighbour listed twice by a point counts once."""
+    rng = np.random.default_rng(m + k + f)
+    src = rng.integers(0, m, (m, k)).astype(np.int32)
+    if k > 1:
+        src[: m // 3, 1] = src[: m // 3, 0]                    # duplicates inside a list
+    hs = rng.integers(-4, 5, (m, f)).astype(np.float32)        # many ties
+    hd = rng.standard_normal((m, f)).astype(np.float32)
+    go = rng.standard_normal((m, f)).astype(np.float32)
+    out, idx_f, idx_i = nat["edge"].edgeconv_forward(k, dev(src.reshape(-1)), dev(hs), dev(hd), return_int_idx=True)
+    got = nat["edge"].edgeconv_backward(dev(go), idx_i, src_ind=dev(src.reshape(-1)))
+    again = nat["edge"].edgeconv_backward(dev(go), idx_i, src_ind=dev(src.reshape(-1)))
+    assert torch.equal(got, again)
+    want = np.zeros((m, f), np.float32)
+    np.add.at(want, (host(idx_i).astype(np.int64), np.arange(f)[None, :].repeat(m, 0)), go)   # row-major, sequential
+    assert np.array_equal(host(got), want)
+    atomic = nat["edge"].edgeconv_backward(dev(go), idx_i)
+    assert_close(host(atomic), want.astype(np.float64), "atomic scatter", atol=1e-5)
