@@ -75,7 +75,7 @@ def ref_ops(monkeypatch):
             edgeconv_forward=_bound("fused_edgeconv", "edgeconv_forward",
                                     lambda k, src_ind, h_src, h_dst, return_int_idx: [T(a) for a in oracle.edgeconv_forward(
                                         k, N(src_ind), N(h_src), N(h_dst))]),
-            edgeconv_backward=_bound("fused_edgeconv", "edgeconv_backward", lambda grad_out, max_idx: T(
+            edgeconv_backward=_bound("fused_edgeconv", "edgeconv_backward", lambda grad_out, max_idx, src_ind: T(
                 oracle.edgeconv_backward(N(grad_out), N(max_idx))))),
     }
     for name, fns in mods.items():
