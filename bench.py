@@ -154,6 +154,9 @@ def main():
                     help="secondary run (test/gat_result.sh:10 uses 0.5); the headline is 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned path even with one rank (sanity check of dgnn_amd.dist)")
+    ap.add_argument("--simulate-rank", default=None, metavar="R/N",
+                    help="time rank R of an N-rank partition ALONE on this GPU, exchanges replaced by local "
+                         "copies of the same size (everything but the wire; results are not meaningful)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,9 +202,14 @@ def main():
     attn_col = (torch.rand((n, H), device=device, generator=gen) - 0.4)
     grad_out = (torch.rand((n, H, F), device=device, generator=gen) - 0.5)
 
-    if use_pg or args.force_dist:
+    if use_pg or args.force_dist or args.simulate_rank:
         from dgnn_amd.dist import PartitionedGAT
-        runner = PartitionedGAT(g, world, rank, device)
+        if args.simulate_rank:
+            sim_r, sim_n = (int(v) for v in args.simulate_rank.split("/"))
+            runner = PartitionedGAT(g, sim_n, sim_r, device, fake_peers=True,
+                                    chunks=int(os.environ.get("DGNN_DIST_CHUNKS", "4")))
+        else:
+            runner = PartitionedGAT(g, world, rank, device)
         lo, hi = runner.lo, runner.hi
         # the rank's inputs live where the operator gathers from (as the GEMM in front of the
         # operator / autograd behind it would produce them): no copy of local rows inside a step
@@ -250,7 +258,7 @@ def main():
     # launches on (dgnn_debug_last_kernel_ms); the whole forward / backward calls are also timed
     # with events on the same (torch current) stream.
     roof = None
-    if not use_pg and not args.force_dist:
+    if not use_pg and not args.force_dist and not args.simulate_rank:
         from dgnn_amd import _lib
         from dgnn_amd.native import fused_gatconv
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -300,7 +308,7 @@ def main():
                 "bwd_kernel_GBps": round(ab["bwd_csc"] / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
                 "survey_3gather_model_GBps": round(ab["survey_total"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
-    if roof is None and (use_pg or args.force_dist):
+    if roof is None and (use_pg or args.force_dist or args.simulate_rank):
         # partitioned run: the same two kernels on this rank's blocks (forward on n_loc rows x
         # nnz_fwd edges, backward on n_loc columns x nnz_bwd edges); rank 0's figures are reported
         from dgnn_amd import _lib
@@ -335,7 +343,11 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:      # a reported baseline of the N = 1 run only
+        if args.simulate_rank:
+            line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
+                                 f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")
+            line["value"] = runner.nnz_fwd / (ms_per_step * 1e-3)
+        if not args.no_cpu_baseline and world == 1 and not args.simulate_rank:      # a reported baseline of the N = 1 run only
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
     if use_pg:

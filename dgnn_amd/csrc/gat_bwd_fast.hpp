@@ -459,13 +459,26 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
     const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
     vec_t acc = V::zero();
     float dsum = 0.f;
-    for (int i = 0; i < npieces; ++i) {
-      const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
-      const float *sp = P.slots + (size_t)s * P.slot_stride;
-      if (ln.active) {
-        vec_add<VEC>(acc, *(const vec_t *)(sp + ln.off));
-        if (P.grad_attn_col != nullptr) dsum += sp[P.HF + ln.head];
+    // loads of FB pieces in flight together, sums in piece order (a hub column has hundreds)
+    constexpr int FB = 8;
+    const bool want_d = P.grad_attn_col != nullptr;
+    for (int i0 = 0; i0 < npieces; i0 += FB) {
+      vec_t v[FB];
+      float d[FB];
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        const int i = min(i0 + j, npieces - 1);
+        const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
+        const float *sp = P.slots + (size_t)s * P.slot_stride;
+        v[j] = *(const vec_t *)(sp + ln.off);
+        d[j] = want_d ? sp[P.HF + ln.head] : 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < FB; ++j)
+        if (i0 + j < npieces) {
+          vec_add<VEC>(acc, v[j]);
+          dsum += d[j];
+        }
     }
     if (ln.active) {
       *(vec_t *)(P.grad_feat + (size_t)c * P.HF + ln.off) = acc;

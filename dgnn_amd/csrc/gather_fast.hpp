@@ -600,22 +600,37 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
     const int head = fid / P.F;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == MODE_GAT) {
+      // A hub row is cut into hundreds of pieces: the loads of FB pieces are issued together, the
+      // arithmetic then runs over them in piece order (same sums as one piece at a time).
+      constexpr int FB = 8;
       float M = DGNN_NEG_INIT;
-      for (int i = 0; i < npieces; ++i) M = fmaxf(M, slot_of(i)[P.HF + head]);
+      for (int i0 = 0; i0 < npieces; i0 += FB) {
+        float m[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) m[j] = slot_of(min(i0 + j, npieces - 1))[P.HF + head];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) M = fmaxf(M, m[j]);
+      }
       float S = 0.f;
-      for (int i = 0; i < npieces; ++i) {
-        const float *sp = slot_of(i);
-        const float fct = expf(sp[P.HF + head] - M);
-        S = fmaf(sp[P.HF + H + head], fct, S);
-        if (active) {
-          if (vec4) {
-            const float4 v = *(const float4 *)(sp + fid);
-            acc[0] = fmaf(v.x, fct, acc[0]); acc[1] = fmaf(v.y, fct, acc[1]);
-            acc[2] = fmaf(v.z, fct, acc[2]); acc[3] = fmaf(v.w, fct, acc[3]);
-          } else {
-            acc[0] = fmaf(sp[fid], fct, acc[0]);
-          }
+      for (int i0 = 0; i0 < npieces; i0 += FB) {
+        float m[FB], sm[FB];
+        float4 v[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+          const float *sp = slot_of(min(i0 + j, npieces - 1));
+          m[j] = sp[P.HF + head];
+          sm[j] = sp[P.HF + H + head];
+          if (vec4) v[j] = *(const float4 *)(sp + fid);
+          else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+          if (i0 + j < npieces) {
+            const float fct = expf(m[j] - M);
+            S = fmaf(sm[j], fct, S);
+            acc[0] = fmaf(v[j].x, fct, acc[0]); acc[1] = fmaf(v[j].y, fct, acc[1]);
+            acc[2] = fmaf(v[j].z, fct, acc[2]); acc[3] = fmaf(v[j].w, fct, acc[3]);
+          }
       }
       if (active) {
         if (vec4)
@@ -629,16 +644,19 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
         }
       }
     } else {
-      for (int i = 0; i < npieces; ++i)
-        if (active) {
-          const float *sp = slot_of(i);
-          if (vec4) {
-            const float4 v = *(const float4 *)(sp + fid);
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-          } else {
-            acc[0] += sp[fid];
-          }
+      constexpr int FB = 8;
+      for (int i0 = 0; i0 < npieces; i0 += FB) {
+        float4 v[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+          const float *sp = slot_of(min(i0 + j, npieces - 1));
+          if (vec4) v[j] = *(const float4 *)(sp + fid);
+          else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+          if (i0 + j < npieces) { acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w; }
+      }
       if (active) {
         if (vec4)
           *(float4 *)(P.out + (size_t)r * P.HF + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);

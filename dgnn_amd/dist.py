@@ -102,6 +102,13 @@ class _Halo:
         b = torch.tensor(owner.bounds, dtype=torch.int64, device=needed_ids.device)
         cut = torch.searchsorted(needed_ids, b)                      # [world+1]
         self.recv_counts = [int(c) for c in (cut[1:] - cut[:-1]).cpu()]
+        if owner._fake_peers:
+            # timing rehearsal of ONE rank's share without peers (bench.py --simulate-rank): pretend
+            # every peer wants from me as many rows as I want from it; WHICH rows does not matter
+            self.send_counts = list(self.recv_counts)
+            self.send_idx = (torch.arange(self.n_needed, dtype=torch.int64, device=needed_ids.device) * 7919
+                             % max(owner.n_loc, 1)).contiguous()
+            return
         self.send_counts = owner._a2a_counts(self.recv_counts)
         wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=needed_ids.device)
         owner._a2a(wanted, needed_ids, self.send_counts, self.recv_counts)   # ids the peers want from me
@@ -185,13 +192,20 @@ class PartitionedGAT:
     world > 1) pipelines the exchange against the compute, see ``_Side``.
     """
 
-    def __init__(self, graph, world, rank, device, ops=None, group=None, mode=None, chunks=None):
+    def __init__(self, graph, world, rank, device, ops=None, group=None, mode=None, chunks=None,
+                 fake_peers=False):
         self.world, self.rank, self.device, self.group = world, rank, device, group
         self.ops = ops if ops is not None else _NativeOps()
         self.mode = mode or os.environ.get("DGNN_DIST_MODE", "halo")
         # one rank needs no collectives; DGNN_DIST_FORCE_COLLECTIVES=1 issues them anyway (a
         # single-GPU rehearsal of the RCCL calls: tests/test_dist.py)
         self._solo = world == 1 and os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") != "1"
+        # fake_peers: this process plays rank `rank` of `world` ALONE, every exchange replaced by a
+        # local copy of the same size -- the results are meaningless, the time is what one rank
+        # spends on everything except the wire (bench.py --simulate-rank)
+        self._fake_peers = bool(fake_peers)
+        if self._fake_peers:
+            self._solo = True
         if self.mode not in ("halo", "allgather"):
             raise ValueError(f"unknown exchange mode {self.mode!r}")
         if chunks is None:
