@@ -36,6 +36,7 @@ SIGNATURES = {
     "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 17 + [_vp, _sz, _vp]),
     "dgnn_gat_backward_packed": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 13 + [_vp, _sz, _vp]),
     "dgnn_dropout_mask": (_i, [_i, _i, _u64, _u64, _vp, _vp]),
+    "dgnn_pack_rows": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dgnn_gat_forward_seeded": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_u64, _u64] + [_vp] * 3 + [_vp, _sz, _vp]),
     "dgnn_gat_backward_seeded": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_u64, _u64] + [_vp] * 9 + [_vp, _sz, _vp]),
     "dgnn_spmm_csr_workspace_bytes": (_sz, [_i, _i, _i, _i]),

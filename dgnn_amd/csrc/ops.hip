@@ -359,6 +359,33 @@ static inline int grid_1d(long long total, int block) {
 }  // namespace dgnn
 
 // ---- deterministic EdgeConv backward: a gather over the REVERSED k-NN lists -----------------
+// out[i,:] = in[idx[i],:] for rows of `wv` vector slots: the pack of the rows a rank sends in the
+// halo exchange (dist.py).  One thread per slot, four independent loads in flight per thread.
+template <class vec_t>
+__global__ __launch_bounds__(256) void k_pack_rows(long long total, int wv, const int *__restrict__ idx,
+                                                   const float *__restrict__ in, float *__restrict__ out) {
+  constexpr int VEC = sizeof(vec_t) / sizeof(float);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  constexpr int U = 4;
+  for (long long e0 = blockIdx.x * (long long)blockDim.x + threadIdx.x; e0 < total; e0 += U * stride) {
+    vec_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long e = e0 + u * stride;
+      if (e < total) {
+        const long long row = e / wv;
+        const int q = (int)(e - row * wv);
+        v[u] = *(const vec_t *)(in + ((size_t)idx[row] * wv + q) * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long e = e0 + u * stride;
+      if (e < total) *(vec_t *)(out + (size_t)e * VEC) = v[u];
+    }
+  }
+}
+
 // grad_src[s,c] = sum over the points r that list s among their neighbours, ascending r, of
 // grad_out[r,c] where max_idx[r,c] == s.  Same values as the scatter of k_edgeconv_bwd, summed in
 // a fixed order and without float atomics (whose 64 lanes land in up to k different rows).
@@ -574,6 +601,24 @@ int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const in
   else
     hipLaunchKernelGGL(k_edgeconv_bwd_gather<1>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
                        col_ptr, row_ind, max_idx, grad_out, grad_src);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_pack_rows(int n_out, int n_in, int width, const int *idx, const float *in, float *out,
+                   void *stream) {
+  if (n_out < 0 || n_in < 0 || width <= 0) return DGNN_ERR_BAD_ARG;
+  if (n_out == 0) return DGNN_OK;
+  if (!idx || !in || !out || n_in == 0) return DGNN_ERR_BAD_ARG;
+  const bool vec4 = (width % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15u) == 0);
+  const int wv = vec4 ? width / 4 : width;
+  const long long total = (long long)n_out * wv;
+  // four slots per thread per trip
+  const int grid = grid_1d((total + 3) / 4, 256);
+  if (vec4)
+    hipLaunchKernelGGL(k_pack_rows<float4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, wv, idx, in, out);
+  else
+    hipLaunchKernelGGL(k_pack_rows<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, wv, idx, in, out);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

@@ -725,6 +725,29 @@ void init(py::module_ &m, const char *what) {
 
 using py::arg;
 
+// -> src[idx]: the rows a rank sends in the halo exchange, packed into one message (dist.py).
+// `out` (keyword): write into the first len(idx) rows of a caller-held buffer instead.
+Tensor pack_rows(const Tensor &src, const Tensor &idx, const OptTensor &out_in) {
+  f32(src, "src"), i32(idx, "idx");
+  if (src.dim() < 1) fail("src must have at least one dim");
+  if (src.device() != idx.device()) fail("src and idx must be on the same device");
+  const int64_t width = src.size(0) > 0 ? src.numel() / src.size(0) : 0;
+  std::vector<int64_t> sizes = src.sizes().vec();
+  sizes[0] = idx.size(0);
+  c10::DeviceGuard guard(src.device());
+  Tensor out = given(out_in) ? *out_in : new_f32(sizes, src);
+  if (given(out_in)) {
+    f32(out, "out");
+    if (out.sizes() != at::IntArrayRef(sizes) || out.device() != src.device())
+      fail("out must be a float32 tensor of shape ", at::IntArrayRef(sizes), " on ", src.device());
+  }
+  if (idx.size(0) == 0 || width == 0) return out;
+  check_rc(API(dgnn_pack_rows)(as_int(idx.size(0), "rows out"), as_int(src.size(0), "rows in"), as_int(width, "width"),
+                               ip(idx), fp(src), fo(out), stream_of(src)),
+           "dgnn_pack_rows");
+  return out;
+}
+
 PYBIND11_MODULE(fused_gatconv, m) {
   py::options options;
   options.disable_function_signatures();
@@ -746,6 +769,8 @@ PYBIND11_MODULE(fused_gatconv, m) {
   def(m, "gat_inference", &gat_inference, "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat",
       "-> out_feat   (fused_gatconv.cpp:38-60)", arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"),
       arg("negative_slope"), arg("in_feat"));
+  def(m, "pack_rows", &pack_rows, "src, idx, out=None", "-> src[idx] (int32 idx, rows of any shape)", arg("src"),
+      arg("idx"), arg("out") = py::none());
   def(m, "gat_row_dot", &gat_row_dot, "grad, out_feat", "-> S [m,h] = <grad[r,h,:], out_feat[r,h,:]>", arg("grad"),
       arg("out_feat"));
   def(m, "gat_backward", &gat_backward,

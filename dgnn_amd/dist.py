@@ -79,6 +79,10 @@ class _NativeOps:
         return self._gat.gat_backward_packed(slope, 0.0, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat,
                                              None, in_feat, attn_col, grad, out=out)
 
+    def pack_rows(self, src, idx):
+        """src[idx] (int32 idx) by the pack kernel: one float4 per lane, four loads in flight."""
+        return self._gat.pack_rows(src, idx)
+
     def transpose(self, ptr, ind, n_cols):
         """(ptr, ind) = CSR of an (r x n_cols) matrix -> (ptr_T [n_cols+1], ind_T, perm)."""
         return self._fmt.csr2csc_int(ptr, ind, n_cols=n_cols)
@@ -108,12 +112,14 @@ class _Halo:
             self.send_counts = list(self.recv_counts)
             self.send_idx = (torch.arange(self.n_needed, dtype=torch.int64, device=needed_ids.device) * 7919
                              % max(owner.n_loc, 1)).contiguous()
+            self.send_idx32 = self.send_idx.to(torch.int32)
             return
         self.send_counts = owner._a2a_counts(self.recv_counts)
         wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=needed_ids.device)
         owner._a2a(wanted, needed_ids, self.send_counts, self.recv_counts)   # ids the peers want from me
         self.send_idx = (wanted - owner.lo).contiguous()                # local row indices, by peer
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < owner.n_loc)
+        self.send_idx32 = self.send_idx.to(torch.int32)      # what the pack kernel reads
 
 
 class _Side:
@@ -286,6 +292,13 @@ class PartitionedGAT:
             if h is not None:
                 h[0].wait()
 
+    def _pack(self, local, h):
+        """The rows of ``local`` the peers want for this chunk, as one contiguous message."""
+        pack = getattr(self.ops, "pack_rows", None)       # injected test back ends have none
+        if pack is not None:
+            return pack(local, h.send_idx32)
+        return local.index_select(0, h.send_idx)
+
     def _start_fetch(self, side, tables, locals_):
         """Start every chunk's exchange, in chunk order: for each chunk the rows the peers need of
         each tensor in ``locals_`` are packed and sent, and the rows this rank needs land directly
@@ -294,7 +307,7 @@ class PartitionedGAT:
         for s, h in enumerate(side.halos):
             hs = []
             for table, local in zip(tables, locals_):
-                send = local.index_select(0, h.send_idx)
+                send = self._pack(local, h)
                 hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
                                     h.send_counts, async_op=True))
             handles.append(hs)

@@ -248,6 +248,13 @@ int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const in
                                const float *grad_out, float *grad_src, void *workspace,
                                size_t workspace_bytes, void *stream);
 
+/* out[i,:] = in[idx[i],:], i < n_out, rows of `width` floats, idx in [0, n_in) (not checked on
+ * the device).  No counterpart in the reference (single GPU): packs the rows a rank sends in the
+ * halo exchange of the row-partitioned multi-GPU path (dgnn_amd/dist.py) into one contiguous
+ * message. */
+int dgnn_pack_rows(int n_out, int n_in, int width, const int *idx, const float *in, float *out,
+                   void *stream);
+
 /* -------------------------------------------------------------------- index work ---- */
 
 size_t dgnn_csr2csc_workspace_bytes(int m, int n, int nnz);

@@ -619,3 +619,25 @@ def test_edgeconv_backward_gathered_is_deterministic_and_exact(nat, m, k, f):
     assert np.array_equal(host(got), want)
     atomic = nat["edge"].edgeconv_backward(dev(go), idx_i)
     assert_close(host(atomic), want.astype(np.float64), "atomic scatter", atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1000, 4, 64), (1000, 4), (513, 1, 7), (300, 4, 4), (64, 5), (10, 2, 256)])
+def test_pack_rows_is_an_exact_row_gather(nat, shape):
+    """dgnn_pack_rows (the send-side pack of the halo exchange): out[i] = src[idx[i]] bit for bit,
+    repeated and unordered ids included; no counterpart in the reference (single GPU)."""
+    rng = np.random.default_rng(3)
+    src = rng.standard_normal(shape).astype(np.float32)
+    for n_out in (0, 1, 777, 5000):
+        idx = rng.integers(0, shape[0], n_out).astype(np.int32)
+        got = nat["gat"].pack_rows(dev(src), dev(idx))
+        assert tuple(got.shape) == (n_out,) + tuple(shape[1:])
+        assert np.array_equal(host(got), src[idx])
+    buf = torch.full((777,) + tuple(shape[1:]), -1.0, device=DEV)
+    idx = rng.integers(0, shape[0], 777).astype(np.int32)
+    ret = nat["gat"].pack_rows(dev(src), dev(idx), out=buf)
+    assert ret.data_ptr() == buf.data_ptr() and np.array_equal(host(buf), src[idx])
+    with pytest.raises(Exception):
+        nat["gat"].pack_rows(dev(src), dev(idx.astype(np.int64)))
+    with pytest.raises(Exception):
+        nat["gat"].pack_rows(dev(src), dev(idx), out=torch.empty(5, device=DEV))
