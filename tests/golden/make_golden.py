@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import oracle  # noqa: E402
-from util import degree_graph, gat_inputs, tiny_graph  # noqa: E402
+from util import degree_graph, gat_inputs, powerlaw_graph, tiny_graph  # noqa: E402
 
 IDX = ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")
 
@@ -59,7 +59,68 @@ def edge_case(name, m, f, k, seed):
                         grad_out=go, out_feat=out, max_idx=idx.astype(np.int32), grad_src=gs)
 
 
+def sddmm_spmm_case(name, g, h, f, seed):
+    """SDDMM (mhsddmm_kernel.cu:5-81), the permuted copy (mhtranspose_kernel.cu:6-14) and the
+    GE-SpMM aggregation (phase 3 of fused_forward_kernel) on one graph."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((g["n"], h, f)).astype(np.float32)
+    b = rng.standard_normal((g["n"], h, f)).astype(np.float32)
+    val = rng.standard_normal((g["nnz"], h)).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, f"sddmm_{name}.npz"), grad=a, feature=b, edge_val=val,
+                        sddmm=oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], a, b),
+                        transposed=oracle.mhtranspose(g["permute"], val),
+                        spmm=oracle.spmm_csr_f64(g["row_ptr"], g["col_ind"], val, b), **{k: g[k] for k in IDX})
+
+
+def index_case(name, n, n_edges, seed):
+    """COO -> CSR by destination -> CSC + permute with scipy ONLY, the way the reference's scripts
+    build them (train_gatconv.py:78-94, test_convert.py:29-30): independent of the oracle."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    key = np.unique(rng.integers(0, n, n_edges).astype(np.int64) * n + rng.integers(0, n, n_edges))
+    dst, src = (key // n).astype(np.int32), (key % n).astype(np.int32)       # sorted by (dst, src)
+    nnz = key.size
+    csr = sp.csr_matrix((np.arange(1, nnz + 1, dtype=np.float64), (dst, src)), shape=(n, n))
+    csc = csr.tocsc()
+    np.savez_compressed(os.path.join(HERE, f"index_{name}.npz"), n=n, coo_row=dst, coo_col=src,
+                        row_ptr=csr.indptr.astype(np.int32), col_ind=csr.indices.astype(np.int32),
+                        col_ptr=csc.indptr.astype(np.int32), row_ind=csc.indices.astype(np.int32),
+                        permute=(csc.data - 1).astype(np.int32))
+
+
+def knn_case(name, batch, points, dim, k, seed, quantised):
+    """k-NN lists by brute force in float64 where that is unambiguous: quantised coordinates make
+    every squared distance an exact small integer in float32 AND float64 (ties -> lower id,
+    itself first); the random case is kept only if no two float64 distances of a query differ by
+    less than 1e-6 relative (so float32 rounding cannot reorder them)."""
+    rng = np.random.default_rng(seed)
+    while True:
+        x = (rng.integers(-3, 4, (batch, points, dim)).astype(np.float32) if quantised
+             else rng.standard_normal((batch, points, dim)).astype(np.float32))
+        out = np.empty((batch, points, k), np.int32)
+        ok = True
+        for b in range(batch):
+            d = ((x[b].astype(np.float64)[:, None, :] - x[b].astype(np.float64)[None, :, :]) ** 2).sum(-1)
+            order = np.lexsort((np.arange(points)[None, :].repeat(points, 0), d), axis=1)   # by d, then id
+            out[b] = order[:, :k] + b * points
+            if not quantised:
+                ds = np.sort(d, axis=1)[:, :k + 1]
+                ok &= bool(np.all(np.diff(ds, axis=1)[:, 1:] > 1e-6 * ds[:, 2:]))
+        if ok:
+            break
+    np.savez_compressed(os.path.join(HERE, f"knn_{name}.npz"), x=x, k=k, src_ind=out.reshape(-1))
+
+
 if __name__ == "__main__":
+    gat_case("hub_h1f64", powerlaw_graph(256, 8, hub_degree=200), 1, 64, 0.0, 8)
+    gat_case("deg64_h1f100", degree_graph(80, [64, 65, 32, 33, 0, 1] + [3] * 74, 9), 1, 100, 0.0, 9)
+    sddmm_spmm_case("deg_h3f6", degree_graph(40, [0, 1, 31, 32, 33, 40, 5, 0] + [2] * 32, 2), 3, 6, 10)
+    sddmm_spmm_case("hub_h4f16", powerlaw_graph(128, 11, hub_degree=100), 4, 16, 11)
+    index_case("n300", 300, 4000, 12)
+    index_case("n50_dense", 50, 3000, 13)
+    knn_case("ties_d3_k20", 2, 96, 3, 20, 14, True)
+    knn_case("random_d3_k20", 2, 128, 3, 20, 15, False)
+    knn_case("random_d64_k8", 1, 100, 64, 8, 16, False)
     gat_case("tiny_h2f8", tiny_graph(), 2, 8, 0.0, 1)
     gat_case("deg_h4f16", degree_graph(40, [0, 1, 31, 32, 33, 40, 5, 0] + [2] * 32, 2), 4, 16, 0.0, 2)
     gat_case("deg_h4f16_drop", degree_graph(40, [0, 1, 31, 32, 33, 40, 5, 0] + [2] * 32, 2), 4, 16, 0.5, 3)

@@ -15,11 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GAT = sorted(glob.glob(os.path.join(HERE, "golden", "gat_*.npz")))
 GMM = sorted(glob.glob(os.path.join(HERE, "golden", "gmm_*.npz")))
 EDGE = sorted(glob.glob(os.path.join(HERE, "golden", "edgeconv_*.npz")))
+SDDMM = sorted(glob.glob(os.path.join(HERE, "golden", "sddmm_*.npz")))
+INDEX = sorted(glob.glob(os.path.join(HERE, "golden", "index_*.npz")))
+KNN = sorted(glob.glob(os.path.join(HERE, "golden", "knn_*.npz")))
 ids = lambda fs: [os.path.basename(f)[:-4] for f in fs]
 
 
 def test_fixtures_present():
-    assert len(GAT) >= 4 and len(GMM) >= 1 and len(EDGE) >= 2
+    assert len(GAT) >= 6 and len(GMM) >= 1 and len(EDGE) >= 2
+    assert len(SDDMM) >= 2 and len(INDEX) >= 2 and len(KNN) >= 3
 
 
 @pytest.mark.parametrize("path", GAT, ids=ids(GAT))
@@ -45,6 +49,31 @@ def test_oracle_edgeconv_vs_golden(path):
     z = np.load(path)
     out, idx = oracle.edgeconv_forward(int(z["k"]), z["src_ind"], z["h_src"], z["h_dst"])
     assert np.array_equal(out, z["out_feat"]) and np.array_equal(idx.astype(np.int32), z["max_idx"])
+
+
+@pytest.mark.parametrize("path", SDDMM, ids=ids(SDDMM))
+def test_oracle_sddmm_spmm_vs_golden(path):
+    z = np.load(path)
+    assert_close(oracle.mhsddmm(z["row_ptr"], z["col_ind"], z["grad"], z["feature"]), z["sddmm"], "sddmm", atol=1e-5)
+    assert np.array_equal(oracle.mhtranspose(z["permute"], z["edge_val"]), z["transposed"])
+    assert np.array_equal(z["transposed"], z["edge_val"][z["permute"]])
+    assert_close(oracle.spmm_csr(z["row_ptr"], z["col_ind"], z["edge_val"], z["feature"]), z["spmm"], "spmm", atol=1e-5)
+
+
+@pytest.mark.parametrize("path", INDEX, ids=ids(INDEX))
+def test_oracle_index_work_vs_scipy_golden(path):
+    """The fixture comes from scipy alone (the reference's own recipe), not from the oracle."""
+    z = np.load(path)
+    assert np.array_equal(oracle.coo2csr(z["coo_row"], int(z["n"])), z["row_ptr"])
+    cp, ri, pm = oracle.csr2csc(z["row_ptr"], z["col_ind"])
+    assert np.array_equal(cp, z["col_ptr"]) and np.array_equal(ri, z["row_ind"]) and np.array_equal(pm, z["permute"])
+
+
+@pytest.mark.parametrize("path", KNN, ids=ids(KNN))
+def test_oracle_knn_vs_float64_golden(path):
+    """The fixture is a float64 brute force with an unambiguous order, not the oracle's chain."""
+    z = np.load(path)
+    assert np.array_equal(oracle.knn_graph(z["x"], int(z["k"])), z["src_ind"])
 
 
 def _dev(a):
@@ -107,3 +136,51 @@ def test_hip_edgeconv_vs_golden(path):
     assert np.array_equal(idx_i.cpu().numpy(), z["max_idx"]), "arg-max ids are bit-exact"
     gs = fe.edgeconv_backward(_dev(z["grad_out"]), idx_i)
     assert_close(gs.cpu().numpy(), z["grad_src"], "grad_src", atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SDDMM, ids=ids(SDDMM))
+def test_hip_sddmm_spmm_vs_golden(path):
+    from dgnn_amd.native import mhsddmm, mhtranspose, spmm
+    z = np.load(path)
+    rp, ci = _dev(z["row_ptr"]), _dev(z["col_ind"])
+    out = mhsddmm.mhsddmm(rp, ci, _dev(z["grad"]), _dev(z["feature"]))
+    assert_close(out.cpu().numpy(), z["sddmm"], "sddmm", atol=1e-5)
+    tr = mhtranspose.mhtranspose(_dev(z["permute"]), _dev(z["edge_val"]))
+    assert np.array_equal(tr.cpu().numpy(), z["transposed"]), "the permuted copy is exact"
+    agg = spmm.spmm_csr(rp, ci, _dev(z["edge_val"]), _dev(z["feature"]))
+    assert_close(agg.cpu().numpy(), z["spmm"], "spmm", atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", INDEX, ids=ids(INDEX))
+def test_hip_index_work_vs_scipy_golden(path):
+    import torch
+    from dgnn_amd.native import format_conversion as fc
+    from dgnn_amd.graph import prepare_graph
+    z = np.load(path)
+    n = int(z["n"])
+    assert np.array_equal(fc.coo2csr(_dev(z["coo_row"]), n).cpu().numpy(), z["row_ptr"])
+    cp, ri, pm = fc.csr2csc_int(_dev(z["row_ptr"]), _dev(z["col_ind"]))
+    assert np.array_equal(cp.cpu().numpy(), z["col_ptr"]) and np.array_equal(ri.cpu().numpy(), z["row_ind"])
+    assert np.array_equal(pm.cpu().numpy(), z["permute"])
+    # the reference's float-valued variant (convert.cpp:16-25): exact below 2^24 entries
+    cp2, ri2, val = fc.csr2csc(_dev(z["row_ptr"]), _dev(z["col_ind"]),
+                               torch.arange(z["col_ind"].size, dtype=torch.float32, device="cuda:0"))
+    assert np.array_equal(cp2.cpu().numpy(), z["col_ptr"]) and np.array_equal(val.cpu().numpy(), z["permute"].astype(np.float32))
+    # whole recipe from shuffled COO (self loops as they are)
+    rng = np.random.default_rng(0)
+    order = rng.permutation(z["coo_row"].size)
+    names = ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")
+    g = dict(zip(names, prepare_graph(_dev(z["coo_col"][order]), _dev(z["coo_row"][order]), n, self_loops="keep")))
+    for k in names:
+        assert np.array_equal(g[k].cpu().numpy(), z[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", KNN, ids=ids(KNN))
+def test_hip_knn_vs_float64_golden(path):
+    from dgnn_amd.native import knn
+    z = np.load(path)
+    got = knn.knn_graph(_dev(z["x"]), int(z["k"]))
+    assert np.array_equal(got.cpu().numpy().reshape(-1), z["src_ind"]), "k-NN ids are bit-exact"
