@@ -105,6 +105,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, 
         tile[e] = (j < jn && f0 + f < dim) ? xc[(size_t)(j0 + j) * dim + f0 + f] : 0.f;
       }
       wave_lds_sync();
+      // (candidate coordinates through wave-uniform scalar loads from global memory instead of
+      // the LDS tile -- the compiler emits s_load_dwordx16 and scalar ALU operands -- measured:
+      // 1.14 -> 1.30 ms at 64 dims, 1.70 -> 2.58 ms at 128: the 102 scalar registers cannot hold
+      // the next candidate while this one is consumed, so the load latency is exposed)
       // (packed-fp32 v_pk_fma_f32 was measured twice: two candidates per instruction gave no gain
       // at 64 dims and ran 2.6x slower at 128 dims from the doubled query registers; two dims of
       // one candidate per instruction -- even/odd chains -- was 5-8 % slower than this scalar loop)
