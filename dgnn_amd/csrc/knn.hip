@@ -21,7 +21,7 @@
 namespace dgnn {
 namespace {
 
-template <int KMAX>
+template <int KMAX, bool MED3>
 struct TopK {
   float d[KMAX];
   int id[KMAX];
@@ -29,11 +29,18 @@ struct TopK {
 #pragma unroll
     for (int t = 0; t < KMAX; ++t) { d[t] = __builtin_inff(); id[t] = -1; }
   }
-  // candidates arrive in ascending id: a strict compare keeps the lower id in front on ties
+  // candidates arrive in ascending id: a strict compare keeps the lower id in front on ties.
+  // The list is sorted, so "newcomer in front of slot t" (dn < d[t]) is monotone in t and every
+  // slot can be rewritten on its own: slot t takes the median of (d[t-1], dn, d[t]) -- itself
+  // when the newcomer goes behind it, the newcomer at the insertion point, its predecessor after
+  // it (equal distances stay behind in their old order) -- and the id follows the same choice.
+  // MED3 is the faster form up to 64 dims (3 dims: 0.30 -> 0.26 ms); with 128 query registers
+  // its extra temporaries cost more than they save (1.58 -> 1.69 ms): there the chained form runs.
   __device__ __forceinline__ void push(float dn, int jn) {
-    if (dn < d[KMAX - 1]) {
-      bool sw = false;   // once the newcomer has found its slot the rest of the list shifts down,
-                         // equal distances included (they must stay behind in their old order)
+    if (MED3) {
+      push_med3(dn, jn);
+    } else if (dn < d[KMAX - 1]) {
+      bool sw = false;   // once the newcomer has found its slot the rest of the list shifts down
 #pragma unroll
       for (int t = 0; t < KMAX; ++t) {
         sw = sw || dn < d[t];
@@ -43,6 +50,24 @@ struct TopK {
         id[t] = sw ? jn : ti;
         dn = sw ? td : dn;
         jn = sw ? ti : jn;
+      }
+    }
+  }
+  __device__ __forceinline__ void push_med3(float dn, int jn) {
+    if (dn < d[KMAX - 1]) {
+      bool front_prev = false;
+      float dprev = -__builtin_inff();
+      int iprev = -1;
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        const float td = d[t];
+        const int ti = id[t];
+        const bool front = dn < td;
+        d[t] = __builtin_amdgcn_fmed3f(dprev, dn, td);
+        id[t] = front ? (front_prev ? iprev : jn) : ti;
+        front_prev = front;
+        dprev = td;
+        iprev = ti;
       }
     }
   }
@@ -58,22 +83,49 @@ struct TopK {
 // the tie rule (a later part only holds higher ids).
 constexpr int KNN_PARTS = DGNN_WAVES_PER_BLOCK;   // 4
 
+// A candidate enters a lane's sorted list only if it beats the list's last entry, but the
+// insertion is a pass over the whole list executed by the wave whenever ANY of its 64 lanes
+// needs it -- with 64 independent queries that is nearly every candidate (P = 1-(1-k/j)^64), and
+// the insertion (~6 vector ops per list slot) costs more than the distance itself below ~64
+// dims.  So accepted candidates are first appended to a per-lane queue of KNN_BUF entries in LDS
+// (two stores) and inserted, in arrival order, only when some lane's queue is full: same list,
+// same ties, a third of the insertion passes.
+constexpr int KNN_BUF = 8;   // 4: 5-15 % slower, 16: the same
+
 static inline int knn_tile(int fc) { return fc >= 128 ? 16 : 32; }    // candidates per LDS tile
 static inline size_t knn_lds_bytes(int fc, bool single, int k) {
   const size_t tile = (size_t)KNN_PARTS * knn_tile(fc) * fc * sizeof(float);
   const size_t carry = single ? 0 : (size_t)KNN_PARTS * knn_tile(fc) * 64 * sizeof(float);
+  const size_t queue = (size_t)KNN_PARTS * KNN_BUF * 64 * 2 * sizeof(float);
   const size_t lists = (size_t)(KNN_PARTS - 1) * k * 64 * 2 * sizeof(float);
-  return tile + carry > lists ? tile + carry : lists;
+  return tile + carry + queue > lists ? tile + carry + queue : lists;
 }
 
 template <int KMAX, int FC, bool SINGLE>
-__global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, int tj,
+__global__ __launch_bounds__(DGNN_BLOCK)
+void k_knn(int points, int dim, int k, int tj,
                                                     const float *__restrict__ x,
                                                     int *__restrict__ src_ind) {
   extern __shared__ __align__(16) float lds[];
   const int part = wave_in_block(), lane = lane_id();
   float *tile = lds + (size_t)part * tj * FC;                                   // [tj][FC]
   float *carry = lds + (size_t)KNN_PARTS * tj * FC + (size_t)part * tj * 64;    // [tj][64], !SINGLE
+  TopK<KMAX, (FC < 128)> best;
+  best.init();
+  float *qd = lds + (size_t)KNN_PARTS * tj * FC + (SINGLE ? 0 : (size_t)KNN_PARTS * tj * 64) +
+              (size_t)part * KNN_BUF * 64 * 2;                                  // [KNN_BUF][64] distances
+  int *qi = (int *)(qd + KNN_BUF * 64);                                         // [KNN_BUF][64] ids
+  int queued = 0;                                                               // per lane
+  auto flush = [&]() {
+    for (int t = 0; t < KNN_BUF; ++t) {
+      if (!__any(t < queued)) break;
+      const bool have = t < queued;
+      const float dn = have ? qd[t * 64 + lane] : __builtin_inff();
+      const int jn2 = have ? qi[t * 64 + lane] : -1;
+      best.push(dn, jn2);
+    }
+    queued = 0;
+  };
   const int b = blockIdx.y;
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < points;
@@ -88,9 +140,6 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, 
 #pragma unroll
     for (int f = 0; f < FC; ++f) xi[f] = (f < dim) ? xi_ptr[f] : 0.f;
   }
-  TopK<KMAX> best;
-  best.init();
-
   for (int j0 = jbeg; j0 < jend; j0 += tj) {
     const int jn = min(tj, jend - j0);
     for (int c = 0; c < nchunks; ++c) {
@@ -112,6 +161,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, 
       // (packed-fp32 v_pk_fma_f32 was measured twice: two candidates per instruction gave no gain
       // at 64 dims and ran 2.6x slower at 128 dims from the doubled query registers; two dims of
       // one candidate per instruction -- even/odd chains -- was 5-8 % slower than this scalar loop)
+      // (also measured without gain at 64 / 128 dims: the candidate's dims as DPP row-broadcast
+      // operands of the subtraction, 16 dims per register, instead of 16-byte LDS broadcast reads
+      // (0.96 -> 0.97 / 1.57 -> 1.73 ms); two candidates per trip as two independent fma chains
+      // (0.96 -> 0.94 / 1.57 -> 3.3 ms, registers).  The loop issues one vector instruction per
+      // ~6 cycles per SIMD against 4 for unpacked fp32 at two waves per SIMD.)
       for (int j = 0; j < jn; ++j) {
         float acc = (SINGLE || c == 0) ? 0.f : carry[j * 64 + lane];
         const float4 *cj = (const float4 *)(tile + j * FC);
@@ -126,13 +180,19 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_knn(int points, int dim, int k, 
           t = xi[4 * f4 + 3] - v.w; acc = fmaf(t, t, acc);
         }
         if (SINGLE || c == nchunks - 1) {
-          best.push(acc, j0 + j);
+          if (acc < best.d[KMAX - 1]) {
+            qd[queued * 64 + lane] = acc;
+            qi[queued * 64 + lane] = j0 + j;
+            ++queued;
+          }
+          if (__any(queued == KNN_BUF)) flush();
         } else {
           carry[j * 64 + lane] = acc;
         }
       }
     }
   }
+  flush();
   // merge: parts 1..3 publish their lists, wave 0 pushes them in part order
   __syncthreads();                                         // every tile is dead from here on
   float *ld = lds;                                         // [part-1][t][64] distances
