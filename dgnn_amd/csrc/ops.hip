@@ -266,6 +266,87 @@ __global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stage1(
   }
 }
 
+// The same stage for K <= MAXK kernels and dim <= MAXD (MoNet: K = 2..3, dim = 2), as a
+// grid-stride kernel: parameters and the 2*K*dim running sums live in registers, every thread
+// walks edges e = tid, tid + stride, ..., and a block reduces ONCE at the end -- the kernel above
+// reduces 2*K*dim times per 256 edges and leaves one partial per 256 edges to stage 2 (Reddit
+// shape, K = 3: 2.2 + 0.76 ms; this one streams the 3.2 GB once).  Per-edge arithmetic and
+// pseudo_out are the same bits; the parameter sums are fixed-order too (fixed grid), only
+// grouped differently.
+#define DGNN_GBP_MAX_BLOCKS 2048
+template <int MAXK, int MAXD>
+__global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stream(
+    int edges, int K, int dim, const float *__restrict__ pseudo, const float *__restrict__ mu,
+    const float *__restrict__ inv_sigma, const float *__restrict__ grad_gauss,
+    float *__restrict__ pseudo_out, float *__restrict__ partial) {
+  __shared__ float red[DGNN_GBP_BLOCK / DGNN_WAVE][2 * MAXK * MAXD];
+  float pm[MAXK][MAXD], ps[MAXK][MAXD], am[MAXK][MAXD], as[MAXK][MAXD];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k)
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+      const bool in = k < K && d < dim;
+      pm[k][d] = in ? mu[k * dim + d] : 0.f;
+      ps[k][d] = in ? inv_sigma[k * dim + d] : 0.f;
+      am[k][d] = 0.f;
+      as[k][d] = 0.f;
+    }
+  const long long stride = (long long)gridDim.x * DGNN_GBP_BLOCK;
+  for (long long e = blockIdx.x * (long long)DGNN_GBP_BLOCK + threadIdx.x; e < edges; e += stride) {
+    float x[MAXD], po[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+      x[d] = d < dim ? pseudo[(size_t)e * dim + d] : 0.f;
+      po[d] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      if (k < K) {
+        float acc = 0.f;                       // gmm_weight(), operand for operand
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+          if (d < dim) {
+            const float tmp = x[d] - pm[k][d];
+            acc = fmaf(tmp * tmp * ps[k][d], ps[k][d], acc);
+          }
+        const float g = (float)exp(-0.5 * (double)acc) * grad_gauss[(size_t)e * K + k];
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+          if (d < dim) {
+            const float sig = ps[k][d];
+            const float diff = x[d] - pm[k][d];
+            const float t = g * diff * sig;
+            po[d] += -t * sig;
+            am[k][d] += t * sig;
+            as[k][d] += -g * diff * diff * sig;
+          }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d)
+      if (d < dim) pseudo_out[(size_t)e * dim + d] = po[d];
+  }
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k)
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+      const float vm = wave_sum(am[k][d]), vs = wave_sum(as[k][d]);
+      if (lane_id() == 0) {
+        red[wave_in_block()][k * MAXD + d] = vm;
+        red[wave_in_block()][MAXK * MAXD + k * MAXD + d] = vs;
+      }
+    }
+  __syncthreads();
+  const int KD = K * dim;
+  if ((int)threadIdx.x < 2 * KD) {
+    const int which = threadIdx.x / KD, idx = threadIdx.x % KD;
+    const int k = idx / dim, d = idx % dim;
+    float sum = 0.f;
+    for (int w = 0; w < DGNN_GBP_BLOCK / DGNN_WAVE; ++w) sum += red[w][which * MAXK * MAXD + k * MAXD + d];
+    partial[((size_t)blockIdx.x * 2 + which) * KD + idx] = sum;
+  }
+}
+
 // Stage 2: one block per (which, k*dim+d) sums the per-block partials in a fixed order.
 __global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stage2(
     int nblocks, int KD, const float *__restrict__ partial, float *__restrict__ mu_out,
@@ -524,10 +605,20 @@ int dgnn_gaussian_backward(int edges, int kernels, int dim, const float *pseudo,
   if (!pseudo || !grad_gauss || !pseudo_out) return DGNN_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < dgnn_gaussian_backward_workspace_bytes(edges, kernels, dim))
     return DGNN_ERR_WORKSPACE;
-  const int nblocks = (edges + DGNN_GBP_BLOCK - 1) / DGNN_GBP_BLOCK;
-  hipLaunchKernelGGL(k_gaussian_bwd_stage1, dim3(nblocks), dim3(DGNN_GBP_BLOCK), 0, st, edges,
-                     kernels, dim, pseudo, mu, inv_sigma, grad_gauss, pseudo_out,
-                     (float *)workspace);
+  int nblocks = (edges + DGNN_GBP_BLOCK - 1) / DGNN_GBP_BLOCK;
+  if (kernels <= 4 && dim <= 2) {
+    nblocks = nblocks < DGNN_GBP_MAX_BLOCKS ? nblocks : DGNN_GBP_MAX_BLOCKS;
+    hipLaunchKernelGGL((k_gaussian_bwd_stream<4, 2>), dim3(nblocks), dim3(DGNN_GBP_BLOCK), 0, st, edges, kernels,
+                       dim, pseudo, mu, inv_sigma, grad_gauss, pseudo_out, (float *)workspace);
+  } else if (kernels <= 8 && dim <= 4) {
+    nblocks = nblocks < DGNN_GBP_MAX_BLOCKS ? nblocks : DGNN_GBP_MAX_BLOCKS;
+    hipLaunchKernelGGL((k_gaussian_bwd_stream<8, 4>), dim3(nblocks), dim3(DGNN_GBP_BLOCK), 0, st, edges, kernels,
+                       dim, pseudo, mu, inv_sigma, grad_gauss, pseudo_out, (float *)workspace);
+  } else {
+    hipLaunchKernelGGL(k_gaussian_bwd_stage1, dim3(nblocks), dim3(DGNN_GBP_BLOCK), 0, st, edges,
+                       kernels, dim, pseudo, mu, inv_sigma, grad_gauss, pseudo_out,
+                       (float *)workspace);
+  }
   DGNN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gaussian_bwd_stage2, dim3(2 * KD), dim3(DGNN_GBP_BLOCK), 0, st, nblocks, KD,
                      (const float *)workspace, mu_out, sigma_out);

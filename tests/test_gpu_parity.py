@@ -641,3 +641,29 @@ def test_pack_rows_is_an_exact_row_gather(nat, shape):
         nat["gat"].pack_rows(dev(src), dev(idx.astype(np.int64)))
     with pytest.raises(Exception):
         nat["gat"].pack_rows(dev(src), dev(idx), out=torch.empty(5, device=DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,d", [(3, 2), (2, 1), (4, 2), (5, 3), (8, 4), (9, 2), (2, 5)])
+@pytest.mark.parametrize("edges", [1, 255, 70_000, 700_001])
+def test_gaussian_backward_streaming_and_block_kernels(nat, k, d, edges):
+    """GaussianBp over the edge counts that decide its launch shape: fewer edges than one block,
+    the grid-stride kernel with every block busy several times (700 001 > 2048 x 256), and the
+    (K, dim) ranges of both streaming variants and of the per-block kernel (K > 8 or dim > 4).
+    pseudo_out is a per-edge value; the [K,dim] sums are checked with the summand mass."""
+    rng = np.random.default_rng(k * 100 + d)
+    pseudo = rng.random((edges, d), dtype=np.float32)
+    mu = (0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    inv_sigma = (1 + 0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    gg = rng.standard_normal((edges, k)).astype(np.float32)
+    po, mo, so = nat["gmm"].GaussianBp(dev(pseudo), dev(mu), dev(inv_sigma), dev(gg))
+    po64, mo64, so64 = oracle.gaussian_bp_f64(pseudo, mu, inv_sigma, gg)
+    _, mo_abs, so_abs = oracle.gaussian_bp_f64(pseudo, mu, inv_sigma, np.abs(gg))
+    assert_close(host(po), po64, "pseudo grad", atol=1e-5)
+    # |summands| of d/d mu are not the sums of |gg| (the diff changes sign): bound them by the
+    # count instead, 4 ulp of sum |terms| <= edges * max|term|
+    bound = 1e-6 * max(1.0, np.sqrt(edges)) + 4 * 6e-8 * edges * 0.05
+    assert_close(host(mo), mo64, "mu grad", rtol=1e-4, atol=bound)
+    assert_close(host(so), so64, "inv_sigma grad", rtol=1e-4, atol=bound)
+    po2, mo2, so2 = nat["gmm"].GaussianBp(dev(pseudo), dev(mu), dev(inv_sigma), dev(gg))
+    assert torch.equal(po, po2) and torch.equal(mo, mo2) and torch.equal(so, so2), "fixed-order sums"
