@@ -84,7 +84,7 @@ def main():
     from dgnn_amd.dist import CloudDataParallel
     dp = CloudDataParallel(model, args.batch_size, world, rank)
     x, y = dp.local(x).contiguous(), dp.local(y).contiguous()      # this rank's clouds
-    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4, fused=True)
     losses = []
 
     def train_iter():

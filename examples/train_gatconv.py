@@ -67,7 +67,7 @@ def main():
                 negative_slope=args.negative_slope).to(device)
     loss_fcn = nn.CrossEntropyLoss()
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
-                                 capturable=args.hip_graph)
+                                 capturable=args.hip_graph, fused=True)   # one launch instead of a foreach chain
     feats, labels = data["features"], data["labels"]
     train_idx = data["train_mask"].nonzero().squeeze(1)      # index list: no host sync inside the epoch
     train_labels = labels[train_idx]
