@@ -73,14 +73,16 @@ static inline int shrink_group_for_small_graphs(int L, int nnz, int min_L) {
 // issue, not bandwidth: they want occupancy, i.e. at most ~6 KiB of LDS per wave (swept on the
 // products and Reddit shapes, tools/sweep_narrow.sh: 4 x 16 forward 6.9 -> 4.5 ms with 256).
 static inline bool narrow_rows(int H, int F) { return F % 4 == 0 && H * F / 4 < DGNN_WAVE; }
-// Tuning override (multiples of 64): DGNN_FWD_L.
+// Tuning override (multiples of 16): DGNN_FWD_L.
 static inline int fast_group_size(int H, int nnz, bool narrow = false) {
   int dflt = H <= 4 ? 512 : 256;
   if (narrow)
     while (dflt > 64 && (size_t)dflt * (H + 2) * sizeof(float) > 6144) dflt >>= 1;
   const int v = env_int("DGNN_FWD_L", 0);
-  if (v >= 64 && v <= 1024 && v % 64 == 0) return v;
-  return shrink_group_for_small_graphs(dflt, nnz, 64);
+  if (v >= 16 && v <= 1024 && v % 16 == 0) return v;
+  // down to 16 edges per wave: a Cora-sized forward 39 -> 19 us (a group is a chain of dependent
+  // latencies: its rows' softmax passes, then its edges four at a time)
+  return shrink_group_for_small_graphs(dflt, nnz, 16);
 }
 static inline size_t fast_lds_bytes(int H, int L) {
   // per wave: weights [L*H] + column ids [L] + flush queue [L]

@@ -667,3 +667,25 @@ def test_gaussian_backward_streaming_and_block_kernels(nat, k, d, edges):
     assert_close(host(so), so64, "inv_sigma grad", rtol=1e-4, atol=bound)
     po2, mo2, so2 = nat["gmm"].GaussianBp(dev(pseudo), dev(mu), dev(inv_sigma), dev(gg))
     assert torch.equal(po, po2) and torch.equal(mo, mo2) and torch.equal(so, so2), "fixed-order sums"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [16, 64, 512])
+@pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
+def test_gat_forward_is_independent_of_the_group_size(nat, name, group, monkeypatch):
+    """The forward picks its neighbour-group size from the edge count (16 edges per wave on
+    small graphs, 512 on large ones); small test graphs would only ever see the small sizes, so
+    the sizes are forced here (DGNN_FWD_L is read at every call).  Same tolerance as everywhere;
+    edge_max bit-exact."""
+    g = GRAPHS[name]
+    in_feat, attn_row, attn_col, _ = gat_inputs(g["n"], 4, 64, seed=3)
+    G = gdev(g)
+    monkeypatch.setenv("DGNN_FWD_L", str(group))
+    out, emax, esum, _ = nat["gat"].gat_forward(dev(attn_row), dev(attn_col), G["row_ptr"], G["col_ind"], 0.2,
+                                                dev(in_feat), 0.0)
+    o64, m64, s64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0, None)
+    m_out = gat_masses(g, attn_row, attn_col, in_feat, np.zeros_like(in_feat), 0.2)[0]
+    assert_close(host(out), o64, "out_feat", mass=m_out)
+    assert_close(host(esum), s64, "edge_sum")
+    _, m32, _ = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0, None)
+    assert np.array_equal(host(emax), m32)
