@@ -273,8 +273,10 @@ extern "C" int dgnn_knn_graph(int batch, int points, int dim, int k, const float
   hipStream_t st = (hipStream_t)stream;
   if (k <= 8) return launch_knn<8>(batch, points, dim, k, x, src_ind, st);
   if (k <= 16) return launch_knn<16>(batch, points, dim, k, x, src_ind, st);
+  if (k <= 20) return launch_knn<20>(batch, points, dim, k, x, src_ind, st);   // the reference's default k
   if (k <= 24) return launch_knn<24>(batch, points, dim, k, x, src_ind, st);
   if (k <= 32) return launch_knn<32>(batch, points, dim, k, x, src_ind, st);
+  if (k <= 40) return launch_knn<40>(batch, points, dim, k, x, src_ind, st);   // its other published k
   if (k <= 48) return launch_knn<48>(batch, points, dim, k, x, src_ind, st);
   return launch_knn<64>(batch, points, dim, k, x, src_ind, st);
 }
