@@ -15,6 +15,8 @@
 // (up to 128 dims at a time) together with its sorted candidate list; a wave streams its share
 // of the cloud's points through LDS in tiles, every lane reads the same candidate element
 // (LDS broadcast, conflict-free), so one 16-byte LDS read feeds 8 vector ops per lane.
+#include <cstdlib>
+
 #include "../../include/dgnn_hip.h"
 #include "common.hpp"
 
@@ -236,10 +238,16 @@ template <int KMAX>
 int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_ind, hipStream_t st) {
   const dim3 grid((unsigned)((points + 63) / 64), (unsigned)batch);
   // Parts per query block: each part keeps its own sorted list, so fewer parts mean fewer list
-  // insertions in total (2 parts: 0.89 -> 0.80 ms at 64 dims), but the chip wants two waves per
-  // SIMD: two parts once there are 1024 query blocks, else four.
+  // insertions in total, but the chip wants its two resident waves per SIMD (2048 waves) and no
+  // second round of blocks: the largest of 4 / 2 / 1 parts that keeps query blocks x parts near
+  // 2048 (tools/knn_parts_ab.py, 64 dims: 32 x 2048 points 0.89 -> 0.80 ms with 2 parts,
+  // 64 x 2048 points 1.71 -> 1.52 ms with 1; 8 x 2048 points want all 4: 0.35 against 1.15 ms).
   const long long qblocks = (long long)((points + 63) / 64) * batch;
-  const int parts = qblocks >= 1024 ? 2 : KNN_MAX_PARTS;
+  int parts = qblocks <= 640 ? KNN_MAX_PARTS : (qblocks <= 1280 ? 2 : 1);
+  if (const char *e = getenv("DGNN_KNN_PARTS")) {       // tuning override: 1, 2 or 4
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) parts = v;
+  }
   const dim3 block(64 * parts);
 #define DGNN_KNN_CASE(FCV)                                                                          \
   if (dim <= FCV) {                                                                                 \

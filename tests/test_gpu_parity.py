@@ -428,7 +428,8 @@ def test_edgeconv_continuous_values_and_operator(nat):
     (3, 50, 3, 5), (2, 300, 3, 20), (2, 257, 64, 20), (1, 1000, 128, 20), (2, 90, 200, 33),
     (1, 64, 16, 64), (5, 20, 1, 1), (1, 31, 7, 31), (2, 2048, 3, 20), (1, 515, 300, 9),
     (2, 1024, 64, 40), (1, 700, 3, 40), (1, 400, 128, 24), (2, 333, 32, 17), (1, 200, 256, 48),   # every list size
-    (64, 1024, 3, 20), (32, 2048, 16, 40), (70, 1000, 130, 8)])   # >= 1024 query blocks: two parts per block
+    (64, 1024, 3, 20), (32, 2048, 16, 40), (70, 1000, 130, 8),    # ~1024 query blocks: two parts per block
+    (64, 2048, 3, 20), (130, 1000, 20, 24)])                      # >= 2048: one
 def test_knn_graph_bit_exact(b, p, dim, k):
     from dgnn_amd.native.knn import knn_graph
     rng = np.random.default_rng(b * 1000 + p + dim)
