@@ -90,3 +90,14 @@ def append_csv(path, line):
     if path:
         with open(path, "a") as f:
             print(line, file=f)
+
+
+def cross_entropy(logits, labels):
+    """nn.CrossEntropyLoss() (mean over rows) as log_softmax + a gather + a mean: torch's
+    nll_loss kernel reduces all rows in ONE workgroup (1.2 ms forward + 0.9 ms backward for the
+    196 k training rows of the products-shaped run); the gather and the mean are ordinary
+    parallel kernels.  Same value up to the order of the float sum."""
+    if logits.shape[0] < 8192:       # launch-bound sizes: the two-kernel library form is shorter
+        return torch.nn.functional.cross_entropy(logits, labels)
+    logp = torch.log_softmax(logits, dim=1)
+    return -logp.gather(1, labels.unsqueeze(1)).mean()

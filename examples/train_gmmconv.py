@@ -6,7 +6,8 @@ import argparse
 import torch
 from torch import nn
 
-from common import accuracy, append_csv, capture_step, max_memory_mb, synthetic_citation, time_epochs
+from common import (accuracy, append_csv, capture_step, cross_entropy, max_memory_mb, synthetic_citation,
+                    time_epochs)
 from dgnn_amd.layers import GMMConv
 
 
@@ -79,7 +80,7 @@ def main():
 
     model = MoNet(data["graph"], data["n_feats"], args.n_hidden, data["n_classes"], args.n_layers,
                   args.pseudo_dim, args.n_kernels, args.dropout).to(device)
-    loss_fcn = nn.CrossEntropyLoss()
+    loss_fcn = cross_entropy
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
                                  capturable=args.hip_graph, fused=True)   # one launch instead of a foreach chain
     feats, labels = data["features"], data["labels"]
