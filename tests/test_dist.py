@@ -58,9 +58,11 @@ def check(parts, spec, h, f):
     los, his = [int(p["lo"]) for p in parts], [int(p["hi"]) for p in parts]
     assert los[0] == 0 and his[-1] == g["n"] and all(his[i] == los[i + 1] for i in range(len(parts) - 1))
     assert sum(int(p["nnz_fwd"]) for p in parts) == g["nnz"] == sum(int(p["nnz_bwd"]) for p in parts)
-    fair = g["nnz"] / len(parts)
+    # balanced by cost = edges + 2 per node (partition_bounds' default node weight)
+    w = 2
+    fair = (g["nnz"] + w * g["n"]) / len(parts)
     max_row = int(np.diff(g["row_ptr"]).max())
-    assert max(int(p["nnz_fwd"]) for p in parts) <= fair + max_row
+    assert max(int(p["nnz_fwd"]) + w * (int(p["hi"]) - int(p["lo"])) for p in parts) <= fair + max_row + w
     out = np.concatenate([p["out"] for p in parts])
     gf = np.concatenate([p["gf"] for p in parts])
     gr = np.concatenate([p["gr"] for p in parts])
@@ -120,9 +122,17 @@ def test_partition_bounds_balance_edges_not_nodes():
     import torch
     from dgnn_amd.dist import partition_bounds
     g = rmat_graph(12, 4000, 60000, 7)
-    b = partition_bounds(torch.from_numpy(g["row_ptr"]), 4)
+    b = partition_bounds(torch.from_numpy(g["row_ptr"]), 4, node_weight=0)
     assert b[0] == 0 and b[-1] == g["n"] and all(b[i] <= b[i + 1] for i in range(4))
     per = [int(g["row_ptr"][b[i + 1]] - g["row_ptr"][b[i]]) for i in range(4)]
     assert max(per) - min(per) <= 2 * int(np.diff(g["row_ptr"]).max())
     nodes = [b[i + 1] - b[i] for i in range(4)]
     assert nodes[0] < nodes[-1], "R-MAT ids are skewed: the first range must hold fewer nodes"
+    # a node also costs `node_weight` edges (dense per-node passes): equal edges + w * nodes
+    w = 3
+    bw = partition_bounds(torch.from_numpy(g["row_ptr"]), 4, node_weight=w)
+    assert bw[0] == 0 and bw[-1] == g["n"] and all(bw[i] <= bw[i + 1] for i in range(4))
+    cost = [int(g["row_ptr"][bw[i + 1]] - g["row_ptr"][bw[i]]) + w * (bw[i + 1] - bw[i]) for i in range(4)]
+    assert max(cost) - min(cost) <= 2 * (int(np.diff(g["row_ptr"]).max()) + w)
+    assert bw[-1] - bw[-2] < nodes[-1], "the range of many short rows shrinks"
+    assert partition_bounds(torch.from_numpy(g["row_ptr"]), 1) == [0, g["n"]]
