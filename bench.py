@@ -8,10 +8,14 @@ over the whole graph with inputs already resident in HBM.  Prints ONE JSON line 
 BASELINE.json's metric (edges/s), the HBM roofline of the dominant kernel and a CPU baseline
 (the oracle's float32 restatement of the reference kernels, timed on the host cores).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the same graph is row-partitioned
-across ranks; each step exchanges only the boundary rows a rank references (all-to-all over RCCL,
-or all-gathers with DGNN_DIST_MODE=allgather; dgnn_amd/dist.py); the work is fixed, so scaling is
-"strong".
+N > 1, one rank per GPU: the same graph is row-partitioned across ranks; each step exchanges only
+the boundary rows a rank references (all-to-all over RCCL, or all-gathers with
+DGNN_DIST_MODE=allgather; dgnn_amd/dist.py); the work is fixed, so scaling is "strong".  The ranks
+come either from torch.distributed.run (RANK / WORLD_SIZE in the environment; --gpus must agree)
+or, when `python bench.py --gpus N` is started plainly, from this process itself: it starts N
+fresh child ranks BEFORE touching the GPU (it never initialises HIP), relays rank 0's JSON line
+and exits non-zero if any rank does.  --dry replaces the workload by one gloo all-reduce on the
+CPU (a check of the launcher alone, tests/test_bench_launcher.py).
 """
 import argparse
 import json
@@ -143,6 +147,53 @@ def cpu_baseline(name, seed=0):
                       f"(n={g['n']}, nnz={g['nnz']}, {H}x{F}), {dt:.2f} s wall"}
 
 
+def self_launch(n_ranks, argv):
+    """Start `n_ranks` child ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1) from a parent that has not touched the GPU, wait for all of them,
+    pass rank 0's stdout through.  No exec: the children are ordinary subprocesses."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_run(args):
+    """The launcher alone: every rank joins a gloo group on the CPU, one all-reduce counts the
+    ranks, rank 0 prints the line.  Touches no GPU."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen, backend = 1, None
+    if "RANK" in os.environ:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen, backend = int(t.item()), dist.get_backend()
+        assert seen == dist.get_world_size() == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "GATConv fwd+bwd edges/s", "value": None, "unit": "edges/s", "dry": True,
+                          "n_gpus": args.gpus, "ranks_seen": seen, "backend": backend}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,11 +208,21 @@ def main():
     ap.add_argument("--simulate-rank", default=None, metavar="R/N",
                     help="time rank R of an N-rank partition ALONE on this GPU, exchanges replaced by local "
                          "copies of the same size (everything but the wire; results are not meaningful)")
+    ap.add_argument("--dry", action="store_true", help="launcher check: gloo all-reduce on the CPU, no GPU work")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1 and not args.simulate_rank:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))        # the parent never initialises the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and ("RANK" in os.environ and world > 1 or args.gpus > 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry:
+        return dry_run(args)
     # a process group also for ONE rank when DGNN_DIST_FORCE_COLLECTIVES=1 (rehearsal of the whole
     # multi-GPU path, RCCL calls included, on a one-GPU box; launch through torch.distributed.run)
     use_pg = world > 1 or (os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
@@ -332,7 +393,10 @@ def main():
     if rank == 0:
         line = {
             "metric": "GATConv fwd+bwd edges/s", "value": nnz / (ms_per_step * 1e-3), "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "ranks_seen": torch.distributed.get_world_size() if use_pg else 1,
+            "backend": (f"{torch.distributed.get_backend()} (RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())})"
+                        if use_pg else None),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "

@@ -3,6 +3,7 @@
 // neighbour-grouped fast path (gather_fast.hpp, gat_bwd_fast.hpp) and the shape-agnostic
 // wave-per-row path (gat_generic.hpp).
 #include <cstdlib>
+#include <mutex>
 
 #include "gat_bwd_fast.hpp"
 #include "gat_generic.hpp"
@@ -280,6 +281,55 @@ int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negati
   return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
                         col_ind, in_feat, attn_drop > 0.f ? edge_mask : nullptr, edge_max, edge_sum,
                         out_feat, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------ entry point that allocates nothing
+// dgnn_gat_forward for callers that cannot bring a workspace (HIP-graph capture, serving loops that
+// forbid allocation): the neighbour-group partial slots live in a file-scope device array.  Every
+// GPU the library runs on holds its own copy of the array at its own address, so the address is
+// looked up once per device (hipGetSymbolAddress with that device current) and kept; host code only
+// ever uses that pointer, never the array's name.
+}  // extern "C"
+static __device__ __align__(256) unsigned char scratch[DGNN_NOALLOC_SCRATCH_BYTES];
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxDevices] = {};
+int scratch_of_current_device(void **out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return DGNN_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void *ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (ptr == nullptr) return DGNN_ERR_WORKSPACE;
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return DGNN_OK;
+}
+}  // namespace
+extern "C" {
+
+int dgnn_gat_forward_noalloc(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                             const float *attn_row, const float *attn_col, const int *row_ptr,
+                             const int *col_ind, const float *in_feat, const float *edge_mask,
+                             float *edge_max, float *edge_sum, float *out_feat, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  // sizes beyond the static array are refused before anything is launched
+  if (fwd_layout(nnz, h, f).total > (size_t)DGNN_NOALLOC_SCRATCH_BYTES) return DGNN_ERR_TOO_LARGE;
+  void *ptr = nullptr;
+  rc = scratch_of_current_device(&ptr);
+  if (rc) return rc;
+  // The kernels write every slot and every task_row0 entry they later read (each group holds at
+  // least one edge, hence one row), so nothing of the previous call's contents needs clearing.
+  return dgnn_gat_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
+                          col_ind, in_feat, edge_mask, edge_max, edge_sum, out_feat, ptr,
+                          (size_t)DGNN_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope, const float *attn_row,

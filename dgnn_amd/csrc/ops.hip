@@ -521,6 +521,7 @@ const char *dgnn_error_string(int code) {
     case DGNN_ERR_UNSUPPORTED: return "shape not supported";
     case DGNN_ERR_WORKSPACE: return "workspace missing or too small";
     case DGNN_ERR_ALIGNMENT: return "pointer not aligned";
+    case DGNN_ERR_TOO_LARGE: return "problem exceeds the static scratch of the no-allocation entry point";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dgnn error";
   }
 }

@@ -36,6 +36,7 @@ extern "C" {
 #define DGNN_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels implement           */
 #define DGNN_ERR_WORKSPACE (-3)     /* workspace NULL or smaller than *_workspace_bytes() */
 #define DGNN_ERR_ALIGNMENT (-4)     /* a pointer is not 4-byte aligned                    */
+#define DGNN_ERR_TOO_LARGE (-5)     /* beyond the static scratch of dgnn_gat_forward_noalloc */
 
 int dgnn_abi_version(void);
 const char *dgnn_error_string(int code);
@@ -69,6 +70,22 @@ int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negati
                      const int *col_ind, const float *in_feat, const float *edge_mask,
                      float *edge_max, float *edge_sum, float *out_feat,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* dgnn_gat_forward WITHOUT a workspace argument and without any allocation.  No counterpart in
+ * the reference (its launcher allocates four tensors per call, fused_gatconv_kernel.cu:371-381);
+ * it exists for callers that cannot allocate or size a workspace: code under HIP-graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The neighbour-group partials live in a
+ * static device array of DGNN_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until
+ * the process ends; its address is looked up once per device on the first call there.  Same
+ * arguments, kernels and bits as dgnn_gat_forward.  Limit: dgnn_gat_forward_workspace_bytes(m,
+ * nnz, h, f) <= DGNN_NOALLOC_SCRATCH_BYTES (about 15 M edges at 4 x 64), else DGNN_ERR_TOO_LARGE and
+ * nothing is launched.  All calls on one GPU share that GPU's array: calls that overlap on one
+ * GPU (two streams, two threads) race; serialise them.  Calls no hipMalloc / hipFree. */
+#define DGNN_NOALLOC_SCRATCH_BYTES (64u << 20)
+int dgnn_gat_forward_noalloc(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                             const float *attn_row, const float *attn_col, const int *row_ptr,
+                             const int *col_ind, const float *in_feat, const float *edge_mask,
+                             float *edge_max, float *edge_sum, float *out_feat, void *stream);
 
 /* Fused GAT inference: forward without mask and without saved statistics.
  * Replaces gat_inference(), fused_gatconv_kernel.cu:671-691 (kernels :391-478, :565-669). */

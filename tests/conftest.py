@@ -26,3 +26,33 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Which parity checks lean on the mass term of util.assert_close: per label, the number of
+    elements compared, how many lie outside the plain rel/abs band (and so pass only through the
+    4-ulp-of-mass term), and the worst error in units of the plain tolerance."""
+    import json
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import TOLERANCE_TALLY
+    except Exception:  # pragma: no cover
+        return
+    if not TOLERANCE_TALLY:
+        return
+    rows = {k: {"elements": v[0], "outside_plain_band": v[1], "worst_err_over_plain_tol": round(v[2], 3),
+                "rtol": v[3], "atol": v[4]} for k, v in sorted(TOLERANCE_TALLY.items())}
+    leaning = {k: v for k, v in rows.items() if v["outside_plain_band"]}
+    terminalreporter.write_line(f"tolerance tally: {len(rows)} labelled checks, {len(leaning)} with elements "
+                                f"outside the plain band (passing through the mass term)")
+    for k, v in leaning.items():
+        terminalreporter.write_line(f"  {k}: {v['outside_plain_band']} / {v['elements']} outside rel {v['rtol']:g} "
+                                    f"abs {v['atol']:g}, worst {v['worst_err_over_plain_tol']}x")
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        tag = "gpu" if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or "") else "cpu"
+        with open(os.path.join(out, f"tolerance_report_{tag}.json"), "w") as fh:
+            json.dump(rows, fh, indent=1)
+    except OSError:  # pragma: no cover
+        pass

@@ -1,6 +1,8 @@
-"""Full-size checks of the fused GAT path at BASELINE.json's headline configuration
-(ogbn-products-shaped R-MAT: 2,449,029 nodes, 62 M edges, 4 heads x 64), where the oracle cannot
-run the whole graph in seconds:
+"""Full-size checks of the fused GAT path at BASELINE.json's two full-graph configurations, where
+the oracle cannot run the whole graph in seconds: the headline (ogbn-products-shaped R-MAT:
+2,449,029 nodes, 62 M edges, 4 heads x 64) and the Reddit-shaped graph of the reference's own
+published run (test/gat_result.csv:11: 232,965 nodes, 114.8 M edges, 4 x 64; average degree 492,
+hub rows of 10^5 neighbours: the hardest regime for rel 1e-5):
 
   * size-independent properties of the operator: rows of the attention matrix sum to one,
     exact homogeneity under scaling by 2 (bit-exact, and with it run-to-run determinism: the
@@ -17,7 +19,7 @@ import pytest
 import torch
 
 import oracle
-from util import assert_close, gat_masses
+from util import assert_close, gat_masses_torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -27,12 +29,19 @@ DEV = "cuda:0"
 H, F, SLOPE = 4, 64, 0.2
 
 
-@pytest.fixture(scope="module")
-def big():
+SHAPES = {"products": (2_449_029, 62_000_000), "reddit": (232_965, 114_848_857)}
+# sampled rows / longest rows / sampled columns handed to the oracle: sized so that the cut-out
+# sub-problem stays at a few million edges (Reddit rows average 492 edges, its 8 longest ~1.5 M)
+SAMPLES = {"products": (3000, 4, 200), "reddit": (2000, 8, 12)}
+
+
+@pytest.fixture(scope="module", params=["products", "reddit"])
+def big(request):
     import bench
     from dgnn_amd.native import fused_gatconv
     dev = torch.device(DEV)
-    g = bench.build_graph("products", dev, seed=0)
+    g = bench.build_graph(request.param, dev, seed=0)
+    g["name"] = request.param
     n = g["n"]
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
@@ -50,7 +59,7 @@ def big():
 
 def test_graph_is_the_headline_shape(big):
     g = big["g"]
-    assert g["n"] == 2_449_029 and g["nnz"] == 62_000_000
+    assert (g["n"], g["nnz"]) == SHAPES[g["name"]]
     rp, ci = g["row_ptr"].long(), g["col_ind"].long()
     assert int(rp[0]) == 0 and int(rp[-1]) == g["nnz"] and bool((rp[1:] >= rp[:-1]).all())
     # strictly ascending columns inside each row (the reference's CSR convention): the key
@@ -140,26 +149,35 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+def sub_masses(big, nodes, sub):
+    """Summand masses of the cut-out sub-problem, float64 on the device."""
+    return gat_masses_torch(torch.from_numpy(sub["row_ptr"]).to(DEV), torch.from_numpy(sub["col_ind"]).to(DEV),
+                            big["ar"][nodes], big["ac"][nodes], big["x"][nodes], big["grad"][nodes], SLOPE)
+
+
 def test_sampled_rows_against_the_oracle(big):
     g = big["g"]
     rp = g["row_ptr"].long()
     deg = rp[1:] - rp[:-1]
     gen = torch.Generator(device=DEV)
     gen.manual_seed(7)
-    rows = torch.randint(0, g["n"], (3000,), device=DEV, generator=gen)
-    rows = torch.unique(torch.cat([rows, torch.topk(deg, 4).indices,            # the longest rows
+    n_rows, n_long, _ = SAMPLES[g["name"]]
+    rows = torch.randint(0, g["n"], (n_rows,), device=DEV, generator=gen)
+    rows = torch.unique(torch.cat([rows, torch.topk(deg, n_long).indices,       # the longest rows
                                    torch.tensor([0, g["n"] - 1], device=DEV)]))
     nodes, sub, rl = cut_rows(g, rows)
     x, ar, ac, grad = (host(big[k][nodes]) for k in ("x", "ar", "ac", "grad"))
+    oracle.set_threads(min(oracle.max_threads(), 16))
     o64, m64, s64 = oracle.gat_forward_f64(ar, ac, sub["row_ptr"], sub["col_ind"], SLOPE, x, 0.0)
     gf64, gr64, gc64 = oracle.gat_backward_f64(SLOPE, 0.0, sub["row_ptr"], sub["col_ind"], None, x, ar, ac, grad)
-    m_out, _, m_gr, _ = gat_masses(sub, ar, ac, x, grad, SLOPE)
-    assert_close(host(big["out"][rows]), o64[rl], "out_feat (sampled rows)", mass=m_out[rl])
-    assert_close(host(big["esum"][rows]), s64[rl], "edge_sum (sampled rows)")
+    m_out, _, m_gr, _ = sub_masses(big, nodes, sub)
+    tag = g["name"]
+    assert_close(host(big["out"][rows]), o64[rl], f"{tag} full size: out_feat (sampled rows)", mass=m_out[rl])
+    assert_close(host(big["esum"][rows]), s64[rl], f"{tag} full size: edge_sum (sampled rows)")
     _, m32, _ = oracle.gat_forward(ar, ac, sub["row_ptr"], sub["col_ind"], SLOPE, x, 0.0)
     assert np.array_equal(host(big["emax"][rows]), m32[rl]), "edge_max is the reference's float max"
     # grad_attn_row[r] needs only row r's edges, grad[r] and the touched in_feat rows
-    assert_close(host(big["gr"][rows]), gr64[rl], "grad_attn_row (sampled rows)", mass=m_gr[rl])
+    assert_close(host(big["gr"][rows]), gr64[rl], f"{tag} full size: grad_attn_row (sampled rows)", mass=m_gr[rl])
 
 
 def test_sampled_columns_against_the_oracle(big):
@@ -168,7 +186,7 @@ def test_sampled_columns_against_the_oracle(big):
     cdeg = cp[1:] - cp[:-1]
     gen = torch.Generator(device=DEV)
     gen.manual_seed(8)
-    cols = torch.randint(0, g["n"], (200,), device=DEV, generator=gen)
+    cols = torch.randint(0, g["n"], (SAMPLES[g["name"]][2],), device=DEV, generator=gen)
     # plus one hub-like column whose sub-problem the oracle still finishes in seconds
     mid = torch.nonzero((cdeg >= 1000) & (cdeg <= 2500)).flatten()
     if mid.numel():
@@ -183,7 +201,9 @@ def test_sampled_columns_against_the_oracle(big):
     nodes, sub, _ = cut_rows(g, rows)
     cl = torch.searchsorted(nodes, cols).cpu().numpy()
     x, ar, ac, grad = (host(big[k][nodes]) for k in ("x", "ar", "ac", "grad"))
+    oracle.set_threads(min(oracle.max_threads(), 16))
     gf64, gr64, gc64 = oracle.gat_backward_f64(SLOPE, 0.0, sub["row_ptr"], sub["col_ind"], None, x, ar, ac, grad)
-    _, m_gf, _, m_gc = gat_masses(sub, ar, ac, x, grad, SLOPE)
-    assert_close(host(big["gf"][cols]), gf64[cl], "grad_feat (sampled columns)", mass=m_gf[cl])
-    assert_close(host(big["gc"][cols]), gc64[cl], "grad_attn_col (sampled columns)", mass=m_gc[cl])
+    _, m_gf, _, m_gc = sub_masses(big, nodes, sub)
+    tag = g["name"]
+    assert_close(host(big["gf"][cols]), gf64[cl], f"{tag} full size: grad_feat (sampled columns)", mass=m_gf[cl])
+    assert_close(host(big["gc"][cols]), gc64[cl], f"{tag} full size: grad_attn_col (sampled columns)", mass=m_gc[cl])

@@ -128,6 +128,12 @@ def gat_inputs(n, h, f, seed):
 MASS_EPS = 4 * 1.1920929e-07   # 4 ulp(float32) of the summand mass, see assert_close
 
 
+# what == label of the check -> [elements, outside the plain band, worst err/plain tol]: which
+# checks actually lean on the mass term (conftest.py prints the table and writes it to
+# gpurun_out/tolerance_report.json at the end of a run)
+TOLERANCE_TALLY = {}
+
+
 def assert_close(actual, expected64, what="", rtol=RTOL, atol=ATOL, mass=None):
     """|actual - expected| <= atol + rtol*|expected| (+ MASS_EPS*mass) elementwise, expected in
     float64.  `mass` (optional, same shape) is sum|terms| of the reduction that produced each
@@ -139,15 +145,56 @@ def assert_close(actual, expected64, what="", rtol=RTOL, atol=ATOL, mass=None):
     e = np.asarray(expected64, np.float64)
     assert a.shape == e.shape, f"{what}: shape {a.shape} vs {e.shape}"
     err = np.abs(a - e)
-    tol = atol + rtol * np.abs(e)
+    plain = atol + rtol * np.abs(e)
+    tol = plain
     if mass is not None:
-        tol = tol + MASS_EPS * np.asarray(mass, np.float64)
+        tol = plain + MASS_EPS * np.asarray(mass, np.float64)
+    rec = TOLERANCE_TALLY.setdefault(what, [0, 0, 0.0, rtol, atol])
+    rec[0] += int(err.size)
+    rec[1] += int((err > plain).sum())
+    if err.size:
+        rec[2] = max(rec[2], float((err / plain).max()))
     bad = err > tol
     if bad.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(
             f"{what}: {bad.sum()} / {bad.size} outside rel {rtol} abs {atol}; worst at {i}: "
             f"got {a[i]!r} want {e[i]!r} (err {err[i]:.3e}, tol {tol[i]:.3e})")
+
+
+def gat_masses_torch(row_ptr, col_ind, attn_row, attn_col, in_feat, grad, slope, p=0.0):
+    """gat_masses on torch tensors (any device), float64: for sub-problems of millions of edges
+    cut out of the full-size graphs.  Same four arrays, as numpy."""
+    import torch
+    rp = row_ptr.long()
+    n = rp.numel() - 1
+    dev = rp.device
+    row = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+    col = col_ind.long()
+    ar, ac = attn_row.double(), attn_col.double()
+    e = ar[row] + ac[col]
+    e = torch.where(e > 0, e, e * slope)
+    h = ar.shape[1]
+    emax = torch.full((n, h), -1e300, device=dev, dtype=torch.float64).scatter_reduce(
+        0, row[:, None].expand(-1, h), e, "amax", include_self=True)
+    ex = torch.exp(e - emax[row])
+    s = torch.zeros((n, h), device=dev, dtype=torch.float64).index_add_(0, row, ex)
+    a = ex / s[row] / (1.0 - p)
+    ax, ag = in_feat.double().abs(), grad.double().abs()
+    m_out, m_gf = torch.zeros_like(ax), torch.zeros_like(ax)
+    g_abs = torch.zeros_like(a)
+    step = 1 << 20                                  # bound the [E,h,f] temporaries
+    for i in range(0, row.numel(), step):
+        sl = slice(i, i + step)
+        xc, gr_ = ax[col[sl]], ag[row[sl]]
+        m_out.index_add_(0, row[sl], a[sl, :, None] * xc)
+        m_gf.index_add_(0, col[sl], a[sl, :, None] * gr_)
+        g_abs[sl] = (gr_ * xc).sum(-1) / (1.0 - p)
+    S_abs = torch.zeros((n, h), device=dev, dtype=torch.float64).index_add_(0, row, a * g_abs)
+    me = a * (g_abs + S_abs[row])
+    m_gr = torch.zeros((n, h), device=dev, dtype=torch.float64).index_add_(0, row, me)
+    m_gc = torch.zeros((n, h), device=dev, dtype=torch.float64).index_add_(0, col, me)
+    return tuple(t.cpu().numpy() for t in (m_out, m_gf, m_gr, m_gc))
 
 
 def gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p=0.0):

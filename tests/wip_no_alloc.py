@@ -1,0 +1,87 @@
+"""dgnn_gat_forward_noalloc (include/dgnn_hip.h): the fused GAT forward with its scratch in a
+static device array, for callers that cannot allocate.  Called straight through the C ABI
+(ctypes) and held to the workspace entry point dgnn_gat_forward bit for bit (same kernels, same
+group size), on two calls in a row, the second on a smaller graph (the array keeps the first
+call's contents), then against the float64 oracle at the parity bar.  Runs last (file name):
+`pytest -x` would otherwise hide every later test behind a failure here."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import assert_close, gat_inputs, gat_masses, powerlaw_graph, rmat_graph
+
+pytestmark = pytest.mark.gpu
+
+SLOPE = 0.2
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _forward_both(g, h, f, seed, p=0.0, check_oracle=True):
+    from dgnn_amd import _lib
+    lib = _lib.lib()
+    n, nnz = g["n"], g["nnz"]
+    in_feat, attn_row, attn_col, _ = gat_inputs(n, h, f, seed)
+    mask = None
+    if p > 0:
+        mask = np.random.default_rng(seed + 1).random((nnz, h), dtype=np.float32)
+    d = dict(ar=_dev(attn_row), ac=_dev(attn_col), rp=_dev(g["row_ptr"]), ci=_dev(g["col_ind"]),
+             x=_dev(in_feat), mk=_dev(mask) if mask is not None else None)
+    st = _lib.stream_of(d["x"])
+
+    def outputs():
+        return (torch.full((n, h), 7.0, device="cuda:0"), torch.full((n, h), 7.0, device="cuda:0"),
+                torch.full((n, h, f), 7.0, device="cuda:0"))
+
+    # existing entry point: caller-provided workspace
+    need = lib.dgnn_gat_forward_workspace_bytes(n, nnz, h, f)
+    ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device="cuda:0")
+    mx0, sm0, out0 = outputs()
+    _lib.check(lib.dgnn_gat_forward(n, nnz, h, f, p, SLOPE, _lib.p(d["ar"]), _lib.p(d["ac"]), _lib.p(d["rp"]),
+                                    _lib.p(d["ci"]), _lib.p(d["x"]), _lib.p(d["mk"]), _lib.p(mx0), _lib.p(sm0),
+                                    _lib.p(out0), _lib.p(ws), need, st), "dgnn_gat_forward")
+    # new entry point: no workspace, no allocation
+    mx1, sm1, out1 = outputs()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    _lib.check(lib.dgnn_gat_forward_noalloc(n, nnz, h, f, p, SLOPE, _lib.p(d["ar"]), _lib.p(d["ac"]),
+                                            _lib.p(d["rp"]), _lib.p(d["ci"]), _lib.p(d["x"]), _lib.p(d["mk"]),
+                                            _lib.p(mx1), _lib.p(sm1), _lib.p(out1), st), "dgnn_gat_forward_noalloc")
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == before
+    assert torch.equal(out0, out1), "out_feat differs from dgnn_gat_forward"
+    assert torch.equal(mx0, mx1) and torch.equal(sm0, sm1), "edge_max / edge_sum differ"
+    if not check_oracle:
+        return
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], SLOPE, in_feat, p, mask)
+    m_out = gat_masses(g, attn_row, attn_col, in_feat, np.zeros_like(in_feat), SLOPE, p)[0]
+    assert_close(out1.cpu().numpy(), o64, "noalloc out_feat vs f64 oracle", mass=m_out)
+
+
+def test_noalloc_forward_matches_workspace_forward_twice_second_smaller():
+    big = rmat_graph(18, 200000, 5000000, 5)      # ~5 M edges: full 512-edge groups, hub rows cut in pieces
+    mid = rmat_graph(14, 12000, 250000, 6)        # checked against the oracle as well
+    small = powerlaw_graph(256, 3)                # empty row, a 200-edge hub, short rows
+    _forward_both(big, 4, 64, seed=0, check_oracle=False)
+    _forward_both(small, 4, 64, seed=1)           # the array still holds the first call's partials
+    _forward_both(mid, 4, 64, seed=4)
+    _forward_both(small, 1, 47, seed=2)           # scalar lanes, other slot stride
+    _forward_both(mid, 8, 8, seed=3, p=0.5)       # narrow rows + explicit dropout mask
+
+
+def test_noalloc_forward_rejects_what_does_not_fit_and_bad_arguments():
+    from dgnn_amd import _lib
+    lib = _lib.lib()
+    n, nnz, h, f = 1000, 40_000_000, 4, 64
+    assert lib.dgnn_gat_forward_workspace_bytes(n, nnz, h, f) > (64 << 20)
+    one = torch.zeros(4, device="cuda:0")
+    args = [_lib.p(one)] * 9
+    rc = lib.dgnn_gat_forward_noalloc(n, nnz, h, f, 0.0, SLOPE, *args, None)
+    assert rc == -5 and b"static scratch" in lib.dgnn_error_string(rc)
+    rc = lib.dgnn_gat_forward_noalloc(10, 10, 4, 64, 0.0, SLOPE, *([None] * 9), None)
+    assert rc == -1
