@@ -349,15 +349,72 @@ int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope, const
                         (hipStream_t)stream);
 }
 
+size_t dgnn_gat_forward_tiles_workspace_bytes(int m, int nnz, int h, int f) {
+  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
+  return align_up(fwd_layout(nnz, h, f).total, 256) + 256;   // + the validation flag
+}
+
+}  // extern "C"
+
+// The list the reference's scheduler loop builds (script/test/test_gat_tb.py:16-26) names every
+// non-empty row once, rows ascending, with tile_in_row = 0, 1, 2 ... per row.  One thread per
+// entry checks it against its predecessor and row_ptr; any violation raises the flag.
+__global__ void k_check_tile_list(int m, int n_tiles, const int *__restrict__ row_ptr,
+                                  const int *__restrict__ tiles, int *__restrict__ flag) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i > n_tiles) return;
+  // entry n_tiles is a virtual terminator (row m): rows after the last entry must be empty
+  const int rid = i < n_tiles ? tiles[2 * i] : m;
+  const int tin = i < n_tiles ? tiles[2 * i + 1] : 0;
+  bool bad = false;
+  if (i < n_tiles) {
+    if (rid < 0 || rid >= m || tin < 0) bad = true;
+    else if (tin >= row_ptr[rid + 1] - row_ptr[rid]) bad = true;   // a tile holds >= 1 edge: tile tin starts at edge >= tin
+  }
+  if (!bad) {
+    const int prid = i > 0 ? tiles[2 * (i - 1)] : -1;
+    const int ptin = i > 0 ? tiles[2 * (i - 1) + 1] : 0;
+    if (i > 0 && (prid < 0 || prid >= m)) {
+      bad = true;                                        // reported by the predecessor's own thread too
+    } else if (rid == prid) {
+      bad = tin != ptin + 1;                             // tiles of a row: consecutive
+    } else if (rid < prid) {
+      bad = true;                                        // rows ascending
+    } else {
+      // a new row starts with its tile 0, and every row skipped in between is empty
+      bad = tin != 0 || row_ptr[rid] != row_ptr[prid + 1];
+    }
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
+extern "C" {
+
 int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
                            const float *attn_row, const float *attn_col, const int *row_ptr,
                            const int *col_ind, const float *in_feat, const int *tile_scheduler,
                            int n_tiles, float *edge_max, float *edge_sum, float *out_feat,
                            void *workspace, size_t workspace_bytes, void *stream) {
-  if (n_tiles < 0 || (n_tiles > 0 && !tile_scheduler)) return DGNN_ERR_BAD_ARG;
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (n_tiles < 0 || (n_tiles > 0 && !tile_scheduler) || (m > 0 && !row_ptr)) return DGNN_ERR_BAD_ARG;
+  const size_t fwd_bytes = align_up(fwd_layout(nnz, h, f).total, 256);
+  if (!workspace || workspace_bytes < fwd_bytes + 256) return DGNN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int *flag = (int *)((char *)workspace + fwd_bytes);
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_check_tile_list, dim3((unsigned)(((long long)n_tiles + 1 + 255) / 256)), dim3(256), 0, st,
+                     m, n_tiles, row_ptr, tile_scheduler, flag);
+  DGNN_LAUNCH_CHECK();
+  int host_flag = 0;
+  e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamSynchronize(st);      // the one entry point that waits: a malformed list is an ERROR CODE
+  if (e != hipSuccess) return (int)e;
+  if (host_flag != 0) return DGNN_ERR_BAD_ARG;
   return dgnn_gat_forward(m, nnz, h, f, 0.f, negative_slope, attn_row, attn_col, row_ptr, col_ind,
-                          in_feat, nullptr, edge_max, edge_sum, out_feat, workspace,
-                          workspace_bytes, stream);
+                          in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, fwd_bytes, stream);
 }
 
 int dgnn_gat_row_dot(int m, int h, int f, const float *grad, const float *out_feat,

@@ -221,7 +221,7 @@ void k_knn(int points, int dim, int k, int tj,
       const int base = b * points;
 #pragma unroll
       for (int t = 0; t < KMAX; ++t)
-        if (t < k) o[t] = base + best.id[t];
+        if (t < k) o[t] = base + (best.id[t] >= 0 ? best.id[t] : i);   // unfilled (NaN / inf distances): the query itself
     }
   }
 }

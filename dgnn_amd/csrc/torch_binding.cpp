@@ -198,7 +198,8 @@ std::vector<Tensor> gat_forward_tb(const Tensor &attn_row, const Tensor &attn_co
   c10::DeviceGuard guard(in_feat.device());
   Tensor out = new_f32({d.m, d.h, d.f}, in_feat);
   Tensor edge_max = new_f32({d.m, d.h}, in_feat), edge_sum = new_f32({d.m, d.h}, in_feat);
-  const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
+  if (tile_scheduler.size(1) != 2) fail("tile_scheduler must be [n_tiles, 2] (row, tile_in_row)");
+  const size_t nb = API(dgnn_gat_forward_tiles_workspace_bytes)(d.m, d.nnz, d.h, d.f);
   Tensor ws = workspace(nb, in_feat);
   check_rc(API(dgnn_gat_forward_tiles)(d.m, d.nnz, d.h, d.f, (float)negative_slope, fp(attn_row), fp(attn_col),
                                        ip(row_ptr), ip(col_ind), fp(in_feat), ip(tile_scheduler),

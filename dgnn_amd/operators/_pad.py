@@ -19,6 +19,15 @@ def pad4(x):
     return torch.nn.functional.pad(x, (0, fp - f))
 
 
+def pad_to(x, width):
+    """[m,h,f] zero-padded to exactly `width` features: the output gradient of a padded forward.
+    The forward decided from ITS tensor's row count whether to pad; the gradient has the row
+    count of the other side of a rectangular block, so it follows the saved tensor's width
+    instead of deciding again (m < PAD_MIN_ROWS <= n would leave the two at different widths)."""
+    f = x.size(2)
+    return x if f == width else torch.nn.functional.pad(x, (0, width - f))
+
+
 def unpad(x, f):
     """View of the first f features (the caller's width)."""
     return x if x.size(2) == f else x[..., :f]

@@ -2,7 +2,7 @@
 import torch
 
 from ..native import fused_gatconv as fused_gat
-from ._pad import pad4 as _pad4
+from ._pad import pad4 as _pad4, pad_to as _pad_to
 
 
 def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):
@@ -78,7 +78,7 @@ class FusedGATFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
          attn_row, attn_col, out_feat) = ctx.saved_tensors
-        grad_out = _pad4(grad_out).contiguous()                # fused_gatconv.py:26
+        grad_out = _pad_to(grad_out, in_feat.size(2)).contiguous()   # fused_gatconv.py:26; the forward's width
         grad_feat, grad_attn_row, grad_attn_col = _backward_with_dropout(
             ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
             attn_row, attn_col, grad_out, out_feat)
@@ -130,7 +130,8 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
          attn_row, attn_col, out_feat, attn_l, attn_r, feat_p) = ctx.saved_tensors
         grad_feat, g_row, g_col = _backward_with_dropout(
             ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask,
-            feat if feat_p is None else feat_p, attn_row, attn_col, _pad4(grad_out).contiguous(), out_feat)
+            feat if feat_p is None else feat_p, attn_row, attn_col,
+            _pad_to(grad_out, out_feat.size(2)).contiguous(), out_feat)
         if grad_feat.size(2) != ctx.f:
             grad_feat = grad_feat[..., :ctx.f].contiguous()
         if ctx.fused_scores:

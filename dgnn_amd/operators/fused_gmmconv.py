@@ -4,7 +4,7 @@ import torch
 from ..native import fused_gmmconv as gmm
 from ..native import mhsddmm
 from ..native import mhtranspose
-from ._pad import pad4, unpad
+from ._pad import pad4, pad_to, unpad
 
 
 def GmmConvFuse(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
@@ -32,7 +32,7 @@ class GmmFuseFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma = ctx.saved_tensors
-        grad_out = pad4(grad_out).contiguous()
+        grad_out = pad_to(grad_out, node_feat.size(2)).contiguous()      # the forward's width
         # one gather pass over the CSC yields both the feature gradient and the Gaussian
         # gradient; shapes outside its range take the reference's three-call sequence
         fused = gmm.gmm_backward_fused(colptr, rowind, permute, node_feat, pseudo, mu, sigma, grad_out)

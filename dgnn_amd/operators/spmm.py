@@ -3,7 +3,7 @@ north_star lists it, the reference only has it inside its fused kernels)."""
 import torch
 
 from ..native import mhsddmm, spmm
-from ._pad import pad4, unpad
+from ._pad import pad4, pad_to, unpad
 
 
 def SpMMCsr(rowptr, colind, colptr, rowind, permute, edge_val, in_feat):
@@ -26,7 +26,7 @@ class SpMMCsrFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         rowptr, colind, colptr, rowind, permute, edge_val, in_feat = ctx.saved_tensors
-        grad_out = pad4(grad_out).contiguous()
+        grad_out = pad_to(grad_out, in_feat.size(2)).contiguous()        # the forward's width
         grad_val = grad_feat = None
         if ctx.needs_input_grad[5]:
             grad_val = mhsddmm.mhsddmm(rowptr, colind, grad_out, in_feat)

@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--num-points", type=int, default=2048)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--emb-dims", default="512,512,256",
+                    help="widths of the classifier head; default = the reference's Model(..., [512, 512, 256], 40), "
+                         "script/train/train_edgeconv.py:244")
     ap.add_argument("--n-epochs", type=int, default=20, help="timed iterations over one synthetic batch")
     ap.add_argument("--lr", type=float, default=0.1)
     ap.add_argument("--dropout", type=float, default=0.5)
@@ -80,7 +83,8 @@ def main():
     torch.manual_seed(0)
     x = torch.randn((args.batch_size, args.num_points, 3), device=device)
     y = torch.randint(0, 40, (args.batch_size,), device=device)
-    model = Model(args.k, [64, 64, 128, 256], [1024, 512, 256], 40, dropout_prob=args.dropout).to(device)   # :244
+    emb_dims = [int(v) for v in args.emb_dims.split(",")]
+    model = Model(args.k, [64, 64, 128, 256], emb_dims, 40, dropout_prob=args.dropout).to(device)   # :244
     from dgnn_amd.dist import CloudDataParallel
     dp = CloudDataParallel(model, args.batch_size, world, rank)
     x, y = dp.local(x).contiguous(), dp.local(y).contiguous()      # this rank's clouds

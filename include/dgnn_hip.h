@@ -97,9 +97,16 @@ int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope,
 /* Tile-scheduled forward.  Replaces gat_forward_tb(), fused_gatconv_kernel.cu:1239-1272
  * (kernel fused_forward_kernel_tb_sr :1153-1237, whose inter-block hand-off through
  * atomics + __threadfence is not a valid grid sync).  `tile_scheduler` [n_tiles,2] is the
- * reference's (row, tile_in_row) list (script/test/test_gat_tb.py:16-26); it is validated
- * for shape only: this library balances rows itself with fixed-size neighbour groups, so
- * the result equals dgnn_gat_forward with attn_drop = 0. */
+ * reference's (row, tile_in_row) list (script/test/test_gat_tb.py:16-26): every NON-EMPTY row
+ * once, rows ascending, tile_in_row = 0, 1, 2 ... per row, each tile starting inside its row.
+ * The list is checked on the device against row_ptr BEFORE anything is computed (rows in range,
+ * order, consecutive tiles, no non-empty row missing, no tile past a row's end); a malformed
+ * list returns DGNN_ERR_BAD_ARG and leaves the outputs untouched (the reference would silently
+ * skip or double-count those edges).  To hand that verdict back as a return code this entry
+ * point -- alone in the library -- waits for the stream, so it cannot be captured into a HIP
+ * graph.  The kernels balance rows with fixed-size neighbour groups whatever the tile size, so
+ * for a well-formed list the result equals dgnn_gat_forward with attn_drop = 0. */
+size_t dgnn_gat_forward_tiles_workspace_bytes(int m, int nnz, int h, int f);
 int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
                            const float *attn_row, const float *attn_col, const int *row_ptr,
                            const int *col_ind, const float *in_feat,

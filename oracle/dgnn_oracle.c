@@ -715,10 +715,15 @@ void oracle_knn(int batch, int points, int dim, int k, const float *x, int *src_
         float bd = 0.f;
         for (int j = 0; j < points; ++j) {
           const float dj = d[j];
+          if (!(dj < INFINITY)) continue; /* NaN or overflowed distance: never a neighbour */
           if (dj < last_d || (dj == last_d && j <= last_j)) continue; /* already taken */
           if (bj < 0 || dj < bd) { bj = j; bd = dj; }
         }
-        src_ind[(size_t)q * k + t] = bj < 0 ? -1 : b * points + bj;
+        /* fewer than k finite distances (a diverged model: NaN / inf features): the remaining
+         * slots name the query itself, so downstream gathers stay in range and the NaNs travel
+         * on as VALUES */
+        src_ind[(size_t)q * k + t] = bj < 0 ? (int)q : b * points + bj;
+        if (bj < 0) continue;
         last_d = bd;
         last_j = bj;
       }

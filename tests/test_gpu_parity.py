@@ -178,6 +178,52 @@ def test_gat_inference_and_tiles(nat, name):
     assert_close(host(esum), s64, "tiled edge_sum")
 
 
+def test_gat_forward_tb_rejects_a_malformed_tile_list(nat):
+    """The tile list is checked on the device against row_ptr (include/dgnn_hip.h:
+    dgnn_gat_forward_tiles): the reference's scheduler list (script/test/test_gat_tb.py:16-26), with
+    any tile size, passes; a list that skips a non-empty row, repeats or reorders tiles, names a
+    row out of range or a tile past its row's end is an error and computes nothing."""
+    import dgnn_amd
+    g = GRAPHS["deg_edges"]              # degrees 0, 1, 31, 32, 33, 63, 64, 65, 0, 2, 96, 5, 3 ...
+    h, f = 4, 64
+    in_feat, attn_row, attn_col, _ = gat_inputs(g["n"], h, f, seed=3)
+    G = gdev(g)
+    args = (dev(attn_row), dev(attn_col), G["row_ptr"], G["col_ind"], 0.2, dev(in_feat))
+    deg = np.diff(g["row_ptr"])
+    ref = nat["gat"].gat_forward(*args, 0.0)
+    for tile in (32, 64, 7):
+        tiles = np.array([(r, t) for r in range(g["n"]) for t in range((deg[r] + tile - 1) // tile)], np.int32)
+        assert torch.equal(nat["gat"].make_tile_scheduler(G["row_ptr"], tile).cpu(), torch.from_numpy(tiles))
+        out, emax, esum = nat["gat"].gat_forward_tb(*args, dev(tiles))
+        assert torch.equal(out, ref[0]) and torch.equal(emax, ref[1]) and torch.equal(esum, ref[2])
+    good = np.array([(r, t) for r in range(g["n"]) for t in range((deg[r] + 31) // 32)], np.int32)
+
+    def edit(fn):
+        t = good.copy()
+        t = fn(t)
+        return dev(np.ascontiguousarray(t, np.int32).reshape(-1, 2))
+
+    row65 = int(np.nonzero(deg == 65)[0][0])
+    first65 = int(np.nonzero(good[:, 0] == row65)[0][0])
+    bad_lists = {
+        "row out of range": edit(lambda t: np.vstack([t, [[g["n"], 0]]])),
+        "negative row": edit(lambda t: np.vstack([[[-1, 0]], t])),
+        "a non-empty row is missing": edit(lambda t: t[t[:, 0] != 2]),
+        "the last row is missing": edit(lambda t: t[t[:, 0] != g["n"] - 1]),
+        "a tile listed twice": edit(lambda t: np.vstack([t[:first65 + 1], t[first65:]])),
+        "a tile of the row skipped": edit(lambda t: np.delete(t, first65 + 1, axis=0)),
+        "rows out of order": edit(lambda t: t[::-1]),
+        "tile past the end of its row": edit(lambda t: np.vstack([t[:first65 + 3], [[row65, 3]], t[first65 + 3:]])),
+        "tile of an empty row": edit(lambda t: np.vstack([[[0, 0]], t])),
+        "empty list for a non-empty graph": dev(np.zeros((0, 2), np.int32)),
+    }
+    for what, ts in bad_lists.items():
+        with pytest.raises(dgnn_amd.DgnnError, match="bad argument"):
+            nat["gat"].gat_forward_tb(*args, ts)
+    with pytest.raises(dgnn_amd.DgnnError):
+        nat["gat"].gat_forward_tb(*args, dev(np.zeros((4, 3), np.int32)))      # not [n_tiles, 2]
+
+
 @pytest.fixture(params=[0, 1 << 30], ids=["padded", "as-is"])
 def pad_rows(request, monkeypatch):
     """Odd widths run zero-padded above PAD_MIN_ROWS rows (operators/_pad.py): both ways here."""
@@ -457,6 +503,31 @@ def test_knn_graph_ties_duplicates_and_errors():
         knn_graph(torch.zeros((1, 4, 3)), 2)                 # CPU tensor: no fallback
 
 
+def test_knn_graph_with_nan_and_inf_points_stays_in_range():
+    """A diverged DGCNN step feeds NaN / inf features to the k-NN in front of the next layer: the
+    ids must stay inside the query's cloud (unfilled slots name the query itself), so EdgeConv's
+    gathers stay in bounds and the NaNs travel on as values."""
+    from dgnn_amd.native.knn import knn_graph
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((3, 70, 5)).astype(np.float32)
+    x[0, 3] = np.nan                      # one bad point: nobody's neighbour, its own list = itself
+    x[1] = np.nan                         # a whole cloud of NaN
+    x[2, :60] = np.inf                    # only 10 finite points: fewer than k finite distances
+    k = 12
+    got = host(knn_graph(dev(x), k))
+    assert np.array_equal(got, oracle.knn_graph(x, k))
+    g3 = got.reshape(3, 70, k)
+    for b in range(3):
+        assert g3[b].min() >= b * 70 and g3[b].max() < (b + 1) * 70
+    assert (g3[0, 3] == 3).all() and not (np.delete(g3[0], 3, 0) == 3).any()
+    assert np.array_equal(g3[1], np.repeat(np.arange(70, 140)[:, None], k, 1))
+    src = dev(got)
+    from dgnn_amd.native import fused_edgeconv
+    h = dev(x.reshape(-1, 5))
+    out, idx = fused_edgeconv.edgeconv_forward(k, src, h, h)     # must not fault
+    assert out.shape == (210, 5)
+
+
 def test_knn_feeds_edgeconv_like_the_reference_model():
     """DGCNN block of script/train/train_edgeconv.py:48-53 with our KNNGraph stand-in."""
     from dgnn_amd.layers import EdgeConv, KNNGraph
@@ -500,6 +571,52 @@ def test_graph_without_edges(nat, n, h, f):
     assert nat["sddmm"].mhsddmm(row_ptr, empty_i, grad, x).shape == (0, h)
     cp, ri, pm = nat["fmt"].csr2csc_int(row_ptr, empty_i)
     assert cp.tolist() == [0] * (n + 1) and ri.numel() == 0 and pm.numel() == 0
+
+
+@pytest.mark.parametrize("m,n", [(40, 70), (70, 40)])
+def test_gat_autograd_operator_on_a_rectangular_block_with_odd_width(nat, m, n, monkeypatch):
+    """m destination rows x n source columns with F = 47 and a padding threshold BETWEEN m and n:
+    the forward pads in_feat by ITS row count, the backward must pad grad_out to that same width
+    whatever its own row count is ('grad must be [m,h,f]')."""
+    import scipy.sparse as sp
+    import dgnn_amd.operators._pad as pad
+    from dgnn_amd.operators import GATConvFuse
+    monkeypatch.setattr(pad, "PAD_MIN_ROWS", 50)
+    h, f, slope = 2, 47, 0.2
+    rng = np.random.default_rng(12)
+    dense = rng.random((m, n)) < 0.15
+    dense[3] = False                                       # an empty row
+    dense[:, 5] = False                                    # an empty column
+    csr = sp.csr_matrix(dense.astype(np.int8))
+    nnz = csr.nnz
+    row_ptr, col_ind = csr.indptr.astype(np.int32), csr.indices.astype(np.int32)
+    csc = sp.csr_matrix((np.arange(nnz, dtype=np.int32), col_ind, row_ptr), shape=(m, n)).tocsc()
+    col_ptr, row_ind, permute = csc.indptr.astype(np.int32), csc.indices.astype(np.int32), csc.data.astype(np.int32)
+    x_np = (rng.random((n, h, f), dtype=np.float32) - 0.4)
+    ar_np = (rng.random((m, h), dtype=np.float32) - 0.6)
+    ac_np = (rng.random((n, h), dtype=np.float32) - 0.4)
+    go_np = (rng.random((m, h, f), dtype=np.float32) - 0.5)
+    x, ar, ac = dev(x_np).requires_grad_(), dev(ar_np).requires_grad_(), dev(ac_np).requires_grad_()
+    out = GATConvFuse(ar, ac, dev(row_ptr), dev(col_ind), dev(col_ptr), dev(row_ind), dev(permute), slope, x, 0.0)
+    assert out.shape == (m, h, f)
+    out.backward(dev(go_np))
+    # float64 torch autograd of the message-passing formula
+    X = torch.tensor(x_np, dtype=torch.float64, requires_grad=True)
+    AR = torch.tensor(ar_np, dtype=torch.float64, requires_grad=True)
+    AC = torch.tensor(ac_np, dtype=torch.float64, requires_grad=True)
+    row = torch.from_numpy(np.repeat(np.arange(m), np.diff(row_ptr))).long()
+    col = torch.from_numpy(col_ind).long()
+    e = torch.nn.functional.leaky_relu(AR[row] + AC[col], slope)
+    emax = torch.full((m, h), -1e300, dtype=torch.float64).scatter_reduce(0, row[:, None].expand(-1, h), e.detach(),
+                                                                          "amax", include_self=True)
+    ex = torch.exp(e - emax[row])
+    a = ex / torch.zeros((m, h), dtype=torch.float64).index_add(0, row, ex)[row]
+    ref = torch.zeros((m, h, f), dtype=torch.float64).index_add(0, row, a[:, :, None] * X[col])
+    ref.backward(torch.tensor(go_np, dtype=torch.float64))
+    assert_close(host(out), ref.detach().numpy(), "rectangular odd width: out")
+    assert_close(host(x.grad), X.grad.numpy(), "rectangular odd width: grad_feat")
+    assert_close(host(ar.grad), AR.grad.numpy(), "rectangular odd width: grad_attn_row", atol=2e-6)
+    assert_close(host(ac.grad), AC.grad.numpy(), "rectangular odd width: grad_attn_col", atol=2e-6)
 
 
 @pytest.mark.parametrize("h,f", [(2, 16), (3, 41), (1, 7)])

@@ -269,3 +269,18 @@ def test_knn_oracle_tie_rule_lower_id_first():
     assert np.array_equal(got, want)
     dup = np.zeros((1, 6, 3), np.float32)              # all points identical
     assert np.array_equal(oracle.knn_graph(dup, 4).reshape(6, 4), np.tile(np.arange(4), (6, 1)))
+
+
+def test_knn_oracle_nan_and_inf_points_name_the_query_itself():
+    """Fewer than k finite distances: the remaining slots hold the query's own id (in range)."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 30, 3)).astype(np.float32)
+    x[0, 5] = np.nan
+    x[1, :25] = np.inf
+    got = oracle.knn_graph(x, 8).reshape(2, 30, 8)
+    assert (got[0, 5] == 5).all() and not (np.delete(got[0], 5, 0) == 5).any()
+    assert got[1].min() >= 30 and got[1].max() < 60
+    for q in range(25, 30):               # finite queries of cloud 1: the 5 finite points, then itself
+        assert sorted(got[1, q, :5]) == list(range(55, 60)) and (got[1, q, 5:] == 30 + q).all()
+    for q in range(25):                   # inf queries: inf - x = inf or NaN for every candidate
+        assert (got[1, q] == 30 + q).all()
