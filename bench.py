@@ -104,22 +104,28 @@ def algorithmic_bytes(n, nnz, h, f):
     return dict(fwd=fwd, bwd_csc=bwd_csc, survey_total=total_model)
 
 
-def measured_traffic(workload, which):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*pmc*: FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  None when no
-    profile of this workload is committed: counters cannot be read from inside the process."""
+def measured_traffic(workload, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    of this workload (profiles/*pmc_hbm_bytes_<workload>.csv: FETCH_SIZE and WRITE_SIZE collected
+    in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM
+    prescribes for gfx950).  Counters cannot be read from inside the process, so the figure is
+    only as fresh as that profile: it is returned with the file it came from, and it is None when
+    no profile of this workload is committed or when the profile does not hold the exact template
+    instantiation just timed (`kernel_name`, from dgnn_debug_last_kernel_name) -- i.e. when the
+    kernel has changed since.  -> (bytes or None, source file or None)"""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_hbm_bytes_{workload}*.csv")))
-    if not files:
-        return None
-    key = "k_bwd_col_gather" if which == "bwd" else "k_fast_row_gather"
-    total = 0.0
-    for row in csv.DictReader(open(files[-1])):
-        if key in row["kernel"]:
-            total += float(row["avg_bytes_corrected"])
-    return total or None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_hbm_bytes_{workload}.csv")), key=os.path.getmtime)
+    if not files or not kernel_name:
+        return None, None
+    src = files[-1]
+    parts = {}
+    for row in csv.DictReader(open(src)):
+        if f"dgnn::{kernel_name}(" in row["kernel"]:
+            parts[row["counter"]] = float(row["avg_bytes_corrected"])
+    if set(parts) != {"FETCH_SIZE", "WRITE_SIZE"}:
+        return None, os.path.relpath(src, ROOT) + f" (no {kernel_name}: stale)"
+    return parts["FETCH_SIZE"] + parts["WRITE_SIZE"], os.path.relpath(src, ROOT)
 
 
 def cpu_baseline(name, seed=0):
@@ -342,11 +348,12 @@ def main():
         tf, tb, kf, kb = tf / reps, tb / reps, kf / reps, kb / reps
         ab = algorithmic_bytes(n, nnz, H, F)
         if kf > 0 and kb > 0:
-            dom = ("k_bwd_col_gather (backward, one CSC gather pass)", ab["bwd_csc"], kb, "bwd") if kb >= kf else \
-                  ("k_fast_row_gather (forward, CSR gather pass)", ab["fwd"], kf, "fwd")
+            dom = ("k_bwd_col_gather (backward, one CSC gather pass)", ab["bwd_csc"], kb, _lib.last_kernel_name(1)) if kb >= kf else \
+                  ("k_fast_row_gather (forward, CSR gather pass)", ab["fwd"], kf, _lib.last_kernel_name(0))
         else:   # generic kernels in use: fall back to the call-level times
-            dom = ("gat_backward call", ab["bwd_csc"], tb, "bwd") if tb >= tf else ("gat_forward call", ab["fwd"], tf, "fwd")
+            dom = ("gat_backward call", ab["bwd_csc"], tb, None) if tb >= tf else ("gat_forward call", ab["fwd"], tf, None)
         achieved = dom[1] / (dom[2] * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.workload, dom[3])
         # device-copy bandwidth of this very GPU, same run: a 2 GiB
         # device-to-device copy, read + written bytes over the event-timed duration
         src = torch.empty(1 << 31, dtype=torch.uint8, device=device)
@@ -360,7 +367,8 @@ def main():
         copy_gbs = 5 * 2 * src.numel() / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
         del src, dst
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom[3]),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_instance": dom[3],
                 "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                 "kernel": dom[0], "algorithmic_bytes": dom[1], "kernel_ms": round(dom[2], 3),
                 "fwd_kernel_ms": round(kf, 3), "bwd_kernel_ms": round(kb, 3),

@@ -27,6 +27,7 @@ SIGNATURES = {
     "dgnn_abi_version": (_i, []),
     "dgnn_error_string": (ctypes.c_char_p, [_i]),
     "dgnn_debug_last_kernel_ms": (_i, [_i, _vp]),
+    "dgnn_debug_last_kernel_name": (ctypes.c_char_p, [_i]),
     "dgnn_gat_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_gat_forward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp, _sz, _vp]),
     "dgnn_gat_forward_noalloc": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp]),
@@ -147,3 +148,10 @@ def last_kernel_ms(which):
     ms = ctypes.c_float(0.0)
     rc = lib().dgnn_debug_last_kernel_ms(int(which), ctypes.byref(ms))
     return float(ms.value) if rc == 0 else None
+
+
+def last_kernel_name(which):
+    """Template instantiation of the most recent dominant-kernel launch as rocprofv3 names it
+    (e.g. "k_bwd_col_gather<4, 4, 4, 0, false>"); None when timing is off."""
+    v = lib().dgnn_debug_last_kernel_name(int(which))
+    return v.decode() if v else None

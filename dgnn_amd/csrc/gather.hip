@@ -2,6 +2,7 @@
 // inference / backward, GE-SpMM and fused GMMConv forward, plus kernel selection between the
 // neighbour-grouped fast path (gather_fast.hpp, gat_bwd_fast.hpp) and the shape-agnostic
 // wave-per-row path (gat_generic.hpp).
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -30,6 +31,7 @@ struct KernelTimer {
   bool on = false, init = false;
   hipEvent_t ev[2][2];
   bool valid[2] = {false, false};
+  char name[2][96] = {{0}, {0}};   // template instantiation of the kernel last timed, as rocprofv3 prints it
 };
 KernelTimer g_timer;
 inline bool timing_on() {
@@ -109,8 +111,12 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
       aligned16(P.attn_col) && aligned16(P.edge_mask) && aligned16(P.edge_max) && aligned16(P.edge_sum))
     ht = P.H;
 #define DGNN_FWD_CASE(VECV, NSV, HTV, STV)                                                     \
-  if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV && steady == STV)                       \
-    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV, STV>), grid, dim3(DGNN_BLOCK), lds, st, P);
+  if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV && steady == STV) {                     \
+    if (MODE == MODE_GAT && timing_on())                                                       \
+      std::snprintf(g_timer.name[0], sizeof(g_timer.name[0]), "k_fast_row_gather<%d, %d, %d, %d, %s>", MODE, VECV, \
+                    NSV, HTV, STV ? "true" : "false");                                         \
+    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV, STV>), grid, dim3(DGNN_BLOCK), lds, st, P); \
+  }
 #define DGNN_FWD_CASES(HTV)                                                                    \
   DGNN_FWD_CASE(4, 1, HTV, true)                                                               \
   DGNN_FWD_CASE(4, 1, HTV, false) DGNN_FWD_CASE(4, 2, HTV, false) DGNN_FWD_CASE(4, 4, HTV, false) \
@@ -225,6 +231,9 @@ void launch_bwd_gather(const BwdParams &P, int hc, int vec, dim3 grid, dim3 bloc
                        hipStream_t st) {
 #define DGNN_BWD_CASE(HC, EPL)                                                                    \
   if (hc == HC && P.L == 64 * EPL) {                                                              \
+    if (BMODE == BWD_GAT && timing_on())                                                          \
+      std::snprintf(g_timer.name[1], sizeof(g_timer.name[1]), "k_bwd_col_gather<%d, %d, %d, %d, %s>", HC, EPL,  \
+                    vec == 4 ? 4 : 1, BMODE, (vec == 4 && P.steady) ? "true" : "false");          \
     if (vec == 4 && P.steady)                                                                     \
       hipLaunchKernelGGL((k_bwd_col_gather<HC, EPL, 4, BMODE, true>), grid, block, lds, st, P);   \
     else if (vec == 4)                                                                            \
@@ -256,6 +265,11 @@ int dgnn_debug_last_kernel_ms(int which, float *ms) {
   if (e != hipSuccess) return (int)e;
   e = hipEventElapsedTime(ms, g_timer.ev[which][0], g_timer.ev[which][1]);
   return e == hipSuccess ? DGNN_OK : (int)e;
+}
+
+const char *dgnn_debug_last_kernel_name(int which) {
+  if (which < 0 || which > 1 || !timing_on() || !g_timer.valid[which]) return nullptr;
+  return g_timer.name[which];
 }
 
 size_t dgnn_gat_forward_workspace_bytes(int m, int nnz, int h, int f) {

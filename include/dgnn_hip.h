@@ -48,6 +48,10 @@ const char *dgnn_error_string(int code);
  * recent such launch in milliseconds (it waits for that launch).  DGNN_ERR_UNSUPPORTED when
  * timing is off or nothing was launched yet. */
 int dgnn_debug_last_kernel_ms(int which, float *ms);
+/* The template instantiation of that launch as a profiler prints it, e.g.
+ * "k_bwd_col_gather<4, 4, 4, 0, false>" (so a counter profile of another instantiation is not
+ * mistaken for this kernel's).  NULL when timing is off or nothing was launched yet. */
+const char *dgnn_debug_last_kernel_name(int which);
 
 /* ------------------------------------------------------------------ fused GAT ---- */
 

@@ -1,11 +1,24 @@
 #!/bin/bash
-# rocprofv3 passes of the headline benchmark on the GPU box (run through gpurun).
-#   gpurun -- bash tools/profile.sh <tag>
-# Kernel trace + stats in one run; HBM byte counters in their own runs (one counter each).
+# rocprofv3 passes of one program on the GPU box (run through gpurun):
+#   gpurun -- bash tools/profile.sh <tag> <name> [program args ...]
+# default program: bench.py on <name> as workload.  Kernel trace + stats in one run; HBM byte
+# counters and the L2 (TCC) hit counters in runs of their own, one --pmc group each, python3
+# directly after `--`.  Output: gpurun_out/prof_<tag>_<name>/{trace,fetch,write,tcc}; condensed into
+# profiles/ by tools/summarize_profile.py <tag> <name>.
 set -u
-tag=${1:-r1}; root=${GRAFT_REPO_ROOT:-$PWD}; out=$root/gpurun_out/prof_$tag; mkdir -p $out
+tag=${1:-r2}; name=${2:-products}; shift 2 || true
+root=${GRAFT_REPO_ROOT:-$PWD}; out=$root/gpurun_out/prof_${tag}_${name}; mkdir -p $out
+if [ $# -eq 0 ]; then
+  long=(python3 $root/bench.py --workload $name --steps 5 --warmup 2 --no-cpu-baseline)
+  short=(python3 $root/bench.py --workload $name --steps 2 --warmup 1 --no-cpu-baseline)
+else
+  long=(python3 "$@"); short=(python3 "$@")
+fi
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_trace.log 2>&1 || exit 1
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1 || exit 1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1 || exit 1
-tail -1 $out/bench_trace.log | cut -c1-600
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- "${long[@]}" > $out/trace.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- "${short[@]}" > $out/fetch.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- "${short[@]}" > $out/write.log 2>&1 || exit 1
+if [ "${DGNN_PROFILE_TCC:-1}" = "1" ]; then
+  timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/tcc -- "${short[@]}" > $out/tcc.log 2>&1 || exit 1
+fi
+tail -1 $out/trace.log | cut -c1-700

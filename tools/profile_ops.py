@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""The program behind the per-operator rocprofv3 passes (tools/profile.sh <tag> <name>
+tools/profile_ops.py <name>): a few launches of ONE operator family at its BASELINE.json shape.
+  gmm_pubmed / gmm_reddit   fused GMMConv fwd + one-pass bwd (K = 3, D = 2, F = 64)
+  edgeconv                  fused EdgeConv fwd / bwd (atomic + deterministic) + k-NN, 32 x 2048, k = 20,
+                            the four DGCNN widths
+  sddmm_spmm                mhsddmm + spmm_csr on the Reddit shape, 4 x 64
+  gat_1x64_products / gat_8x8_products / gat_1x64_reddit   narrow fused GAT fwd + bwd"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+REPS = int(os.environ.get("DGNN_PROFILE_REPS", "3"))
+
+
+def gmm(workload):
+    from dgnn_amd.operators import GmmConvFuse
+    if workload == "pubmed":
+        from util import random_graph
+        g = random_graph(19717, 88648, 0)
+        g = {k: (torch.from_numpy(v).to(dev) if hasattr(v, "shape") else v) for k, v in g.items()}
+    else:
+        g = bench.build_graph("reddit", dev)
+    K, D, F = 3, 2, 64
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    x = torch.randn((g["n"], K, F), device=dev, generator=gen).requires_grad_()
+    ps = torch.rand((g["nnz"], D), device=dev, generator=gen).requires_grad_()
+    mu = (0.1 * torch.randn((K, D), device=dev, generator=gen)).requires_grad_()
+    sg = torch.ones((K, D), device=dev).requires_grad_()
+    go = torch.randn((g["n"], K, F), device=dev, generator=gen)
+    for _ in range(REPS):
+        x.grad = ps.grad = mu.grad = sg.grad = None
+        GmmConvFuse(g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], x, ps, mu, sg).backward(go)
+
+
+def edgeconv():
+    from dgnn_amd.native import fused_edgeconv as fe
+    from dgnn_amd.native.knn import knn_graph
+    batch, pts, k = 32, 2048, 20
+    m = batch * pts
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    for dim, f in ((3, 64), (64, 64), (64, 128), (128, 256)):
+        x = torch.randn((batch, pts, dim), device=dev, generator=gen)
+        hs = torch.randn((m, f), device=dev, generator=gen)
+        hd = torch.randn((m, f), device=dev, generator=gen)
+        go = torch.randn((m, f), device=dev, generator=gen)
+        for _ in range(REPS):
+            src = knn_graph(x, k)
+            out, idx_f, idx_i = fe.edgeconv_forward(k, src, hs, hd, return_int_idx=True)
+            fe.edgeconv_backward(go, idx_i)
+            fe.edgeconv_backward(go, idx_i, src_ind=src)
+
+
+def sddmm_spmm():
+    from dgnn_amd.native import mhsddmm, spmm
+    g = bench.build_graph("reddit", dev)
+    H, F = 4, 64
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    x = torch.rand((g["n"], H, F), device=dev, generator=gen) - 0.4
+    go = torch.rand((g["n"], H, F), device=dev, generator=gen) - 0.5
+    val = torch.rand((g["nnz"], H), device=dev, generator=gen)
+    for _ in range(REPS):
+        spmm.spmm_csr(g["row_ptr"], g["col_ind"], val, x)
+        mhsddmm.mhsddmm(g["row_ptr"], g["col_ind"], go, x)
+
+
+def gat(H, F, workload):
+    from dgnn_amd.native import fused_gatconv as fg
+    g = bench.build_graph(workload, dev)
+    n = g["n"]
+    x = torch.rand((n, H, F), device=dev) - 0.4
+    ar, ac = torch.rand((n, H), device=dev) - 0.6, torch.rand((n, H), device=dev) - 0.4
+    go = torch.rand((n, H, F), device=dev) - 0.5
+    for _ in range(REPS):
+        out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
+        fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], emax, esum,
+                        emask, x, ar, ac, go, out_feat=out)
+
+
+if __name__ == "__main__":
+    w = sys.argv[1]
+    if w.startswith("gmm_"):
+        gmm(w[4:])
+    elif w == "edgeconv":
+        edgeconv()
+    elif w == "sddmm_spmm":
+        sddmm_spmm()
+    elif w.startswith("gat_"):
+        _, hf, wl = w.split("_")
+        h, f = hf.split("x")
+        gat(int(h), int(f), wl)
+    else:
+        raise SystemExit(f"unknown operator set {w}")
+    torch.cuda.synchronize()

@@ -1,37 +1,56 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (tools/profile.sh) into the committed summaries:
-profiles/<tag>_kernel_stats_<workload>.csv and profiles/<tag>_pmc_hbm_bytes_<workload>.csv."""
+"""Condense gpurun_out/prof_<tag>_<name>/ (tools/profile.sh) into the committed summaries:
+profiles/<tag>_kernel_stats_<name>.csv, profiles/<tag>_pmc_hbm_bytes_<name>.csv and, when the TCC
+pass ran, profiles/<tag>_pmc_l2_hit_<name>.csv (hits / (hits + misses) of the L2 per kernel)."""
 import csv
 import glob
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
-workload = sys.argv[2] if len(sys.argv) > 2 else "products"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+name = sys.argv[2] if len(sys.argv) > 2 else "products"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+src = os.path.join(root, "gpurun_out", f"prof_{tag}_{name}")
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 
 f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
 rows = list(csv.reader(open(f)))
 keep = [rows[0]] + [r for r in rows[1:] if "dgnn::" in r[0]]
-csv.writer(open(os.path.join(root, "profiles", f"{tag}_kernel_stats_{workload}.csv"), "w")).writerows(keep)
+csv.writer(open(os.path.join(root, "profiles", f"{tag}_kernel_stats_{name}.csv"), "w")).writerows(keep)
 for r in keep[1:]:
-    print(f"{r[0][:64]:64s} calls={r[1]:>3s} avg_us={float(r[3]) / 1e3:10.1f}")
+    print(f"{r[0][:72]:72s} calls={r[1]:>4s} avg_us={float(r[3]) / 1e3:10.1f}")
+
+
+def per_kernel(sub):
+    """{counter: {kernel: [values per dispatch]}} of one --pmc pass."""
+    fs = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+    acc = {}
+    if fs:
+        for r in csv.DictReader(open(fs[0])):
+            if "dgnn::" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], {}).setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return acc
+
 
 out = [["kernel", "counter", "dispatches", "avg_counter_value_KB", "avg_bytes_corrected", "note"]]
-for name, counter, corr in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
-    f = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))[0]
-    acc = {}
-    for r in csv.DictReader(open(f)):
-        if "dgnn::" in r["Kernel_Name"]:
-            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in acc.items():
+for sub, counter, corr in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
+    for k, v in per_kernel(sub).get(counter, {}).items():
         avg = sum(v) / len(v)
         note = ("x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM); "
                 "calibrated on k_bwd_rowstat's known 5.0 GB read") if corr == 2 else "exact for 16 B/lane stores"
         out.append([k, counter, len(v), f"{avg:.1f}", f"{avg * 1024 * corr:.4e}", note])
-csv.writer(open(os.path.join(root, "profiles", f"{tag}_pmc_hbm_bytes_{workload}.csv"), "w")).writerows(out)
+csv.writer(open(os.path.join(root, "profiles", f"{tag}_pmc_hbm_bytes_{name}.csv"), "w")).writerows(out)
 for r in out[1:]:
-    if "gather" in r[0] or "rowstat" in r[0] or "row_sum" in r[0]:
-        print(r[1], r[0][:50], r[4])
+    if float(r[4]) > 5e7:
+        print(f"{r[1]:10s} {r[0][:60]:60s} {float(r[4]) / 1e9:8.3f} GB")
+
+tcc = per_kernel("tcc")
+if tcc:
+    hit, miss = tcc.get("TCC_HIT_sum", {}), tcc.get("TCC_MISS_sum", {})
+    rows = [["kernel", "dispatches", "avg_TCC_HIT_sum", "avg_TCC_MISS_sum", "l2_hit_rate"]]
+    for k in hit:
+        h, m = sum(hit[k]) / len(hit[k]), sum(miss.get(k, [0])) / max(len(miss.get(k, [0])), 1)
+        rows.append([k, len(hit[k]), f"{h:.0f}", f"{m:.0f}", f"{h / max(h + m, 1):.4f}"])
+        if h + m > 1e6:
+            print(f"L2 hit {h / max(h + m, 1):6.3f}  {k[:70]}")
+    csv.writer(open(os.path.join(root, "profiles", f"{tag}_pmc_l2_hit_{name}.csv"), "w")).writerows(rows)
