@@ -115,7 +115,17 @@ __device__ __forceinline__ float drop_scale(float w, float attn_drop) {
 struct DropRng {
   unsigned long long seed, offset;
   int on;
+  // optional DEVICE pair {seed, offset} read by the kernel at launch instead of the two values
+  // above: a launch captured into a HIP graph then draws from whatever the pair holds at each
+  // replay (the *_seeded_dev entry points), not from values frozen into the kernel arguments
+  const unsigned long long *dev;
 };
+__device__ __forceinline__ void drop_resolve(DropRng &r) {
+  if (r.dev != nullptr) {
+    r.seed = r.dev[0];
+    r.offset = r.dev[1];
+  }
+}
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {

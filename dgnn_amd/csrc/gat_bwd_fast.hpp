@@ -167,6 +167,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
+  if (BMODE == BWD_GAT) drop_resolve(P.rng);
   constexpr size_t per_wave_floats = (size_t)L * HC * 2 + (size_t)L * 5;
   float2 *cell = (float2 *)(lds_raw + (size_t)wib * per_wave_floats);  // [L][HC] {±w, B -> d}
   unsigned *kof = (unsigned *)(cell + (size_t)L * HC);                  // [L] column ordinal | END

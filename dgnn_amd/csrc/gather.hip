@@ -140,7 +140,7 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
                    const float *attn_row, const float *attn_col, const int *row_ptr,
                    const int *col_ind, const float *in_feat, const float *edge_mask,
                    float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                   size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0}) {
+                   size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0, nullptr}) {
   if (m == 0) return DGNN_OK;
   // the H == 4 kernels move the per-row / per-edge scalars as float4
   const bool h4_aligned = aligned16(attn_col) && aligned16(attn_row) && aligned16(edge_mask) &&
@@ -373,7 +373,7 @@ size_t dgnn_gat_forward_tiles_workspace_bytes(int m, int nnz, int h, int f) {
 // The list the reference's scheduler loop builds (script/test/test_gat_tb.py:16-26) names every
 // non-empty row once, rows ascending, with tile_in_row = 0, 1, 2 ... per row.  One thread per
 // entry checks it against its predecessor and row_ptr; any violation raises the flag.
-__global__ void k_check_tile_list(int m, int n_tiles, const int *__restrict__ row_ptr,
+__global__ void k_check_tile_list(int m, int n_tiles, int tile_nnz, const int *__restrict__ row_ptr,
                                   const int *__restrict__ tiles, int *__restrict__ flag) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i > n_tiles) return;
@@ -383,7 +383,7 @@ __global__ void k_check_tile_list(int m, int n_tiles, const int *__restrict__ ro
   bool bad = false;
   if (i < n_tiles) {
     if (rid < 0 || rid >= m || tin < 0) bad = true;
-    else if (tin >= row_ptr[rid + 1] - row_ptr[rid]) bad = true;   // a tile holds >= 1 edge: tile tin starts at edge >= tin
+    else if ((long long)tin * tile_nnz >= row_ptr[rid + 1] - row_ptr[rid]) bad = true;   // the tile starts past its row's end
   }
   if (!bad) {
     const int prid = i > 0 ? tiles[2 * (i - 1)] : -1;
@@ -395,8 +395,10 @@ __global__ void k_check_tile_list(int m, int n_tiles, const int *__restrict__ ro
     } else if (rid < prid) {
       bad = true;                                        // rows ascending
     } else {
-      // a new row starts with its tile 0, and every row skipped in between is empty
+      // a new row starts with its tile 0, every row skipped in between is empty, and the
+      // previous row's last listed tile reaches that row's end
       bad = tin != 0 || row_ptr[rid] != row_ptr[prid + 1];
+      if (i > 0 && ((long long)ptin + 1) * tile_nnz < row_ptr[prid + 1] - row_ptr[prid]) bad = true;
     }
   }
   if (bad) atomicOr(flag, 1);
@@ -407,10 +409,11 @@ extern "C" {
 int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
                            const float *attn_row, const float *attn_col, const int *row_ptr,
                            const int *col_ind, const float *in_feat, const int *tile_scheduler,
-                           int n_tiles, float *edge_max, float *edge_sum, float *out_feat,
+                           int n_tiles, int tile_nnz, float *edge_max, float *edge_sum, float *out_feat,
                            void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
+  if (tile_nnz <= 0) return DGNN_ERR_BAD_ARG;
   if (n_tiles < 0 || (n_tiles > 0 && !tile_scheduler) || (m > 0 && !row_ptr)) return DGNN_ERR_BAD_ARG;
   const size_t fwd_bytes = align_up(fwd_layout(nnz, h, f).total, 256);
   if (!workspace || workspace_bytes < fwd_bytes + 256) return DGNN_ERR_WORKSPACE;
@@ -419,7 +422,7 @@ int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
   hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_check_tile_list, dim3((unsigned)(((long long)n_tiles + 1 + 255) / 256)), dim3(256), 0, st,
-                     m, n_tiles, row_ptr, tile_scheduler, flag);
+                     m, n_tiles, tile_nnz, row_ptr, tile_scheduler, flag);
   DGNN_LAUNCH_CHECK();
   int host_flag = 0;
   e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -460,7 +463,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
                              const float *out_feat, const float *row_dot, const float4 *packed,
                              float *grad_feat, float *grad_attn_row, float *grad_attn_col,
                              void *workspace, size_t workspace_bytes, void *stream,
-                             DropRng rng = DropRng{0, 0, 0}) {
+                             DropRng rng = DropRng{0, 0, 0, nullptr}) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (n < 0) return DGNN_ERR_BAD_ARG;
@@ -615,6 +618,7 @@ int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative
 
 // Materialise the mask the seeded entry points regenerate (one thread per Philox block of four).
 __global__ void k_dropout_mask(long long total, DropRng rng, float *__restrict__ mask) {
+  drop_resolve(rng);
   for (long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x; b * 4 < total;
        b += (long long)gridDim.x * blockDim.x) {
     const float4 v = drop_uniform4(rng, (unsigned long long)b);
@@ -631,7 +635,7 @@ int dgnn_dropout_mask(int nnz, int h, uint64_t seed, uint64_t offset, float *mas
   long long g = ((total + 3) / 4 + 255) / 256;
   if (g > 65536) g = 65536;
   hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, total,
-                     DropRng{seed, offset, 1}, mask);
+                     DropRng{seed, offset, 1, nullptr}, mask);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }
@@ -651,7 +655,43 @@ int dgnn_gat_forward_seeded(int m, int nnz, int h, int f, float attn_drop, float
     return DGNN_ERR_WORKSPACE;
   return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr, col_ind,
                         in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, workspace_bytes,
-                        (hipStream_t)stream, DropRng{seed, offset, attn_drop > 0.f ? 1 : 0});
+                        (hipStream_t)stream, DropRng{seed, offset, attn_drop > 0.f ? 1 : 0, nullptr});
+}
+
+int dgnn_gat_forward_seeded_dev(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                                const float *attn_row, const float *attn_col, const int *row_ptr,
+                                const int *col_ind, const float *in_feat, const uint64_t *rng_state,
+                                float *edge_max, float *edge_sum, float *out_feat, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (m == 0) return DGNN_OK;
+  if (!attn_row || !row_ptr || !out_feat || !edge_max || !edge_sum) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!attn_col || !in_feat || !col_ind)) return DGNN_ERR_BAD_ARG;
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
+  if (attn_drop > 0.f && (!rng_state || ((uintptr_t)rng_state & 7u))) return DGNN_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+    return DGNN_ERR_WORKSPACE;
+  return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr, col_ind,
+                        in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, workspace_bytes,
+                        (hipStream_t)stream,
+                        DropRng{0, 0, attn_drop > 0.f ? 1 : 0, (const unsigned long long *)rng_state});
+}
+
+int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float negative_slope,
+                                 float attn_drop, const int *row_ptr, const int *col_ind,
+                                 const int *col_ptr, const int *row_ind, const int *permute,
+                                 const float *edge_max, const float *edge_sum, const uint64_t *rng_state,
+                                 const float *in_feat, const float *attn_row, const float *attn_col,
+                                 const float *grad, const float *out_feat, const float *row_dot,
+                                 float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+  if (attn_drop > 0.f && (!rng_state || ((uintptr_t)rng_state & 7u))) return DGNN_ERR_BAD_ARG;
+  return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
+                           permute, edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, out_feat,
+                           row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
+                           workspace_bytes, stream,
+                           DropRng{0, 0, 1, (const unsigned long long *)rng_state});
 }
 
 int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative_slope,
@@ -666,7 +706,7 @@ int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative
   return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
                            permute, edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, out_feat,
                            row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
-                           workspace_bytes, stream, DropRng{seed, offset, 1});
+                           workspace_bytes, stream, DropRng{seed, offset, 1, nullptr});
 }
 
 // ------------------------------------------------------------------------- GE-SpMM / GMM

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
+  if (MODE == MODE_GAT) drop_resolve(P.rng);
   const int L = P.L, H = P.H;
   float *sc = lds_raw + (size_t)wib * L * (H + 2);        // [L][H] score terms -> weights
   unsigned *cidx = (unsigned *)(sc + (size_t)L * H);      // [L] column id | ROWEND

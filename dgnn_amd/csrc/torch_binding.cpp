@@ -192,7 +192,7 @@ std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, 
 // -> [out_feat, edge_max, edge_sum]   (fused_gatconv.cpp:68-95)
 std::vector<Tensor> gat_forward_tb(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
                                    const Tensor &col_ind, double negative_slope, const Tensor &in_feat,
-                                   const Tensor &tile_scheduler) {
+                                   const Tensor &tile_scheduler, int64_t tile) {
   const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
   i32(tile_scheduler, "tile_scheduler", 2);
   c10::DeviceGuard guard(in_feat.device());
@@ -203,7 +203,7 @@ std::vector<Tensor> gat_forward_tb(const Tensor &attn_row, const Tensor &attn_co
   Tensor ws = workspace(nb, in_feat);
   check_rc(API(dgnn_gat_forward_tiles)(d.m, d.nnz, d.h, d.f, (float)negative_slope, fp(attn_row), fp(attn_col),
                                        ip(row_ptr), ip(col_ind), fp(in_feat), ip(tile_scheduler),
-                                       as_int(tile_scheduler.size(0), "tiles"), fo(edge_max), fo(edge_sum), fo(out),
+                                       as_int(tile_scheduler.size(0), "tiles"), as_int(tile, "tile"), fo(edge_max), fo(edge_sum), fo(out),
                                        ptr<void>(ws), nb, stream_of(in_feat)),
            "dgnn_gat_forward_tiles");
   return {out, edge_max, edge_sum};
@@ -365,6 +365,75 @@ py::object gat_backward_seeded(double negative_slope, double attn_drop, const Te
       stream_of(in_feat));
   if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
   check_rc(rc, "dgnn_gat_backward_seeded");
+  return py::cast(std::vector<Tensor>{grad_feat, grad_attn_row, grad_attn_col});
+}
+
+// ---- the seeded pair with (seed, offset) in DEVICE memory (include/dgnn_hip.h: dgnn_*_seeded_dev):
+// rng_state = int64 tensor [2] on the inputs' device.  What a HIP-graph capture needs: scalar
+// arguments are frozen into a captured launch, a device pair is read anew at every replay.
+const uint64_t *rng_state_ptr(const Tensor &rng_state, const Tensor &like) {
+  if (!rng_state.defined() || !rng_state.is_cuda() || rng_state.scalar_type() != at::kLong || rng_state.numel() != 2 ||
+      !rng_state.is_contiguous() || rng_state.device() != like.device())
+    fail("rng_state must be a contiguous int64 tensor [2] = {seed, offset} on the inputs' device");
+  return reinterpret_cast<const uint64_t *>(rng_state.data_ptr());
+}
+
+py::object gat_forward_seeded_dev(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
+                                  const Tensor &col_ind, double negative_slope, const Tensor &in_feat, double attn_drop,
+                                  const Tensor &rng_state, const OutList &outs) {
+  const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
+  const uint64_t *state = rng_state_ptr(rng_state, in_feat);
+  c10::DeviceGuard guard(in_feat.device());
+  Tensor out = out_f32(outs, 0, {d.m, d.h, d.f}, in_feat, "out_feat");
+  Tensor edge_max = out_f32(outs, 1, {d.m, d.h}, in_feat, "edge_max");
+  Tensor edge_sum = out_f32(outs, 2, {d.m, d.h}, in_feat, "edge_sum");
+  const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
+  Tensor ws = workspace(nb, in_feat);
+  const int rc = API(dgnn_gat_forward_seeded_dev)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
+                                                  fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat),
+                                                  state, fo(edge_max), fo(edge_sum), fo(out), ptr<void>(ws), nb,
+                                                  stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gat_forward_seeded_dev");
+  return py::cast(std::vector<Tensor>{out, edge_max, edge_sum});
+}
+
+py::object gat_backward_seeded_dev(double negative_slope, double attn_drop, const Tensor &row_ptr,
+                                   const Tensor &col_ind, const Tensor &col_ptr, const Tensor &row_ind,
+                                   const Tensor &permute, const Tensor &edge_max, const Tensor &edge_sum,
+                                   const Tensor &rng_state, const Tensor &in_feat, const Tensor &attn_row,
+                                   const Tensor &attn_col, const Tensor &grad, const OptTensor &out_feat,
+                                   const OptTensor &row_dot, const OutList &outs) {
+  i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
+  i32(permute, "permute");
+  f32(edge_max, "edge_max", 2), f32(edge_sum, "edge_sum", 2), f32(in_feat, "in_feat", 3);
+  f32(attn_row, "attn_row", 2), f32(attn_col, "attn_col", 2), f32(grad, "grad", 3);
+  const uint64_t *state = rng_state_ptr(rng_state, in_feat);
+  const int m = as_int(row_ptr.size(0) - 1, "rows"), nnz = as_int(col_ind.size(0), "nnz");
+  const int n = as_int(col_ptr.size(0) - 1, "columns");
+  const int h = as_int(in_feat.size(1), "heads"), f = as_int(in_feat.size(2), "features");
+  if (in_feat.size(0) != n || attn_col.size(0) != n)
+    fail("gat_backward_seeded_dev: in_feat/attn_col rows must equal len(col_ptr)-1");
+  if (grad.size(0) != m || attn_row.size(0) != m || edge_max.size(0) != m || edge_sum.size(0) != m)
+    fail("gat_backward_seeded_dev: grad/attn_row/edge_max/edge_sum rows must equal len(row_ptr)-1");
+  if (grad.size(1) != h || grad.size(2) != f) fail("gat_backward_seeded_dev: grad must be [m,h,f]");
+  if (row_ind.size(0) != nnz || permute.size(0) != nnz) fail("gat_backward_seeded_dev: row_ind / permute must hold nnz entries");
+  if (given(out_feat)) f32(*out_feat, "out_feat", 3);
+  if (given(row_dot)) f32(*row_dot, "row_dot", 2);
+  const int have = (given(out_feat) || given(row_dot)) ? 1 : 0;
+  c10::DeviceGuard guard(in_feat.device());
+  Tensor grad_feat = out_f32(outs, 0, {n, h, f}, in_feat, "grad_feat");
+  Tensor grad_attn_row = out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row");
+  Tensor grad_attn_col = out_f32(outs, 2, {n, h}, in_feat, "grad_attn_col");
+  const size_t nb = API(dgnn_gat_backward_workspace_bytes)(m, n, nnz, h, f, have);
+  Tensor ws = workspace(nb, in_feat);
+  const int rc = API(dgnn_gat_backward_seeded_dev)(
+      m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind), ip(col_ptr), ip(row_ind),
+      ip(permute), fp(edge_max), fp(edge_sum), state, fp(in_feat), fp(attn_row), fp(attn_col), fp(grad),
+      fp(out_feat), fp(row_dot), fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb,
+      stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gat_backward_seeded_dev");
   return py::cast(std::vector<Tensor>{grad_feat, grad_attn_row, grad_attn_col});
 }
 
@@ -761,9 +830,11 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
       arg("attn_drop"), arg("edge_mask") = py::none(), arg("out") = py::none());
   def(m, "gat_forward_tb", &gat_forward_tb,
-      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, tile_scheduler",
-      "-> [out_feat, edge_max, edge_sum]   (fused_gatconv.cpp:68-95)", arg("attn_row"), arg("attn_col"),
-      arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"), arg("tile_scheduler"));
+      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, tile_scheduler, tile=32",
+      "-> [out_feat, edge_max, edge_sum]   (fused_gatconv.cpp:68-95).  tile_scheduler must be the list the\n"
+      "reference's scheduler builds for tiles of `tile` edges (make_tile_scheduler); checked on the device.",
+      arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
+      arg("tile_scheduler"), arg("tile") = 32);
   def(m, "make_tile_scheduler", &make_tile_scheduler, "row_ptr, tile=32",
       "-> int32 [n_tiles, 2]: the (row, tile_in_row) list of script/test/test_gat_tb.py:16-26", arg("row_ptr"),
       arg("tile") = 32);
@@ -793,6 +864,20 @@ PYBIND11_MODULE(fused_gatconv, m) {
       "-> [out_feat, edge_max, edge_sum], or None where the seeded kernels do not apply.",
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
       arg("attn_drop"), arg("seed"), arg("offset") = 0, arg("out") = py::none());
+  def(m, "gat_forward_seeded_dev", &gat_forward_seeded_dev,
+      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, rng_state, out=None",
+      "gat_forward_seeded with {seed, offset} read from the int64 device tensor rng_state [2] at launch\n"
+      "(capturable into a HIP graph: every replay draws from what the tensor then holds).",
+      arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
+      arg("attn_drop"), arg("rng_state"), arg("out") = py::none());
+  def(m, "gat_backward_seeded_dev", &gat_backward_seeded_dev,
+      "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, rng_state, "
+      "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",
+      "gat_backward_seeded with the device pair rng_state its forward used.",
+      arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
+      arg("permute"), arg("edge_max"), arg("edge_sum"), arg("rng_state"), arg("in_feat"), arg("attn_row"),
+      arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
+      arg("out") = py::none());
   def(m, "gat_backward_seeded", &gat_backward_seeded,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, seed, offset, "
       "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",

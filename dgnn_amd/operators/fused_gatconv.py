@@ -5,16 +5,53 @@ from ..native import fused_gatconv as fused_gat
 from ._pad import pad4 as _pad4, pad_to as _pad_to
 
 
+# Device-resident {seed, counter} per GPU for dropout under HIP-graph capture.  A captured launch
+# freezes its scalar arguments: a host-drawn seed would replay ONE mask forever.  Under capture the
+# operator therefore copies the pair (device-to-device, captured), advances the counter (captured)
+# and hands the COPY to the kernels, forward and backward: every replay draws a fresh mask and
+# the backward sees its forward's.  The pair is created by the first eager dropout call on a
+# device (or init_capture_rng): it cannot be created inside a capture (host-to-device copy).
+_CAPTURE_RNG = {}
+
+
+def init_capture_rng(device, seed=None):
+    """Create (or reseed) the device {seed, counter} pair dropout draws from under HIP-graph
+    capture.  Called implicitly by any eager call with attn_drop > 0."""
+    device = torch.device(device)
+    if seed is None:
+        seed = int(torch.randint(0, 1 << 62, (1,)).item())
+    _CAPTURE_RNG[device] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+    return _CAPTURE_RNG[device]
+
+
 def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):
     """-> (out_feat, edge_max, edge_sum, edge_mask or None, seed or None).  With attn_drop > 0 the
     mask is not drawn and kept ([nnz,h] floats: 1 GB per layer at the products shape, what the
     reference saves, fused_gatconv.py:18) but regenerated in the backward from a 62-bit seed taken
     from torch's CPU generator (reproducible under torch.manual_seed, no device sync); shapes the
-    seeded kernels do not take get the SAME mask materialised."""
+    seeded kernels do not take get the SAME mask materialised.  Under HIP-graph capture the seed
+    is a device tensor instead (see _CAPTURE_RNG)."""
     if not attn_drop > 0:
         out, emax, esum, mask = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope,
                                                       in_feat, attn_drop)
         return out, emax, esum, mask, None
+    if torch.cuda.is_current_stream_capturing():
+        from .._lib import DgnnError
+        state = _CAPTURE_RNG.get(in_feat.device)
+        if state is None:
+            raise DgnnError("attn_drop > 0 under HIP-graph capture needs the device seed created beforehand: run "
+                            "one eager step first (the usual warm-up) or call "
+                            "dgnn_amd.operators.fused_gatconv.init_capture_rng(device)")
+        mine = state.clone()                      # captured copy: what THIS forward and its backward read
+        state[1:].add_(1)                         # captured: the next forward / the next replay draws another mask
+        res = fused_gat.gat_forward_seeded_dev(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat,
+                                               attn_drop, mine)
+        if res is None:
+            raise DgnnError("attn_drop > 0 under HIP-graph capture: this shape is outside the seeded kernels "
+                            "(heads > 8 or misaligned rows); capture without dropout or run it eagerly")
+        return res[0], res[1], res[2], None, mine
+    if in_feat.device not in _CAPTURE_RNG:
+        init_capture_rng(in_feat.device)
     seed = int(torch.randint(0, 1 << 62, (1,)).item())
     res = fused_gat.gat_forward_seeded(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, seed)
     if res is not None:
@@ -27,6 +64,10 @@ def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, 
 
 def _backward_with_dropout(ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask,
                            in_feat, attn_row, attn_col, grad_out, out_feat):
+    if isinstance(ctx.seed, torch.Tensor):        # forward ran under capture: device pair
+        return fused_gat.gat_backward_seeded_dev(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr,
+                                                 row_ind, permute, edge_max, edge_sum, ctx.seed, in_feat, attn_row,
+                                                 attn_col, grad_out, out_feat=out_feat)
     if ctx.seed is not None:
         res = fused_gat.gat_backward_seeded(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind,
                                             permute, edge_max, edge_sum, ctx.seed, 0, in_feat, attn_row, attn_col,

@@ -101,10 +101,11 @@ int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope,
 /* Tile-scheduled forward.  Replaces gat_forward_tb(), fused_gatconv_kernel.cu:1239-1272
  * (kernel fused_forward_kernel_tb_sr :1153-1237, whose inter-block hand-off through
  * atomics + __threadfence is not a valid grid sync).  `tile_scheduler` [n_tiles,2] is the
- * reference's (row, tile_in_row) list (script/test/test_gat_tb.py:16-26): every NON-EMPTY row
- * once, rows ascending, tile_in_row = 0, 1, 2 ... per row, each tile starting inside its row.
- * The list is checked on the device against row_ptr BEFORE anything is computed (rows in range,
- * order, consecutive tiles, no non-empty row missing, no tile past a row's end); a malformed
+ * reference's (row, tile_in_row) list (script/test/test_gat_tb.py:16-26) for tiles of `tile_nnz`
+ * edges (32 in the reference): every NON-EMPTY row, rows ascending, tile_in_row = 0 ..
+ * ceil(degree / tile_nnz) - 1.  The list is checked on the device against row_ptr BEFORE anything
+ * is computed (rows in range and in order, tiles consecutive, no non-empty row missing, no tile
+ * starting past its row's end, the last listed tile of a row reaching that end); a malformed
  * list returns DGNN_ERR_BAD_ARG and leaves the outputs untouched (the reference would silently
  * skip or double-count those edges).  To hand that verdict back as a return code this entry
  * point -- alone in the library -- waits for the stream, so it cannot be captured into a HIP
@@ -114,7 +115,7 @@ size_t dgnn_gat_forward_tiles_workspace_bytes(int m, int nnz, int h, int f);
 int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
                            const float *attn_row, const float *attn_col, const int *row_ptr,
                            const int *col_ind, const float *in_feat,
-                           const int *tile_scheduler, int n_tiles,
+                           const int *tile_scheduler, int n_tiles, int tile_nnz,
                            float *edge_max, float *edge_sum, float *out_feat,
                            void *workspace, size_t workspace_bytes, void *stream);
 
@@ -198,6 +199,27 @@ int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative
                              const float *row_dot, float *grad_feat, float *grad_attn_row,
                              float *grad_attn_col, void *workspace, size_t workspace_bytes,
                              void *stream);
+
+/* The seeded entry points with (seed, offset) read FROM DEVICE MEMORY at launch: rng_state points
+ * to two uint64 {seed, offset} (8-byte aligned).  A launch captured into a HIP graph bakes its
+ * scalar arguments in, so the by-value variants above would replay ONE mask forever; with the pair
+ * in device memory the caller (or a captured kernel of its own) advances it between replays and
+ * every replay draws a fresh mask, the backward reading the pair its forward used.  Same bits as
+ * the by-value variants for the same pair.  No counterpart in the reference (cuRAND on the host,
+ * fused_gatconv_kernel.cu:333-341, cannot be captured at all). */
+int dgnn_gat_forward_seeded_dev(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                                const float *attn_row, const float *attn_col, const int *row_ptr,
+                                const int *col_ind, const float *in_feat, const uint64_t *rng_state,
+                                float *edge_max, float *edge_sum, float *out_feat, void *workspace,
+                                size_t workspace_bytes, void *stream);
+int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float negative_slope,
+                                 float attn_drop, const int *row_ptr, const int *col_ind,
+                                 const int *col_ptr, const int *row_ind, const int *permute,
+                                 const float *edge_max, const float *edge_sum, const uint64_t *rng_state,
+                                 const float *in_feat, const float *attn_row, const float *attn_col,
+                                 const float *grad, const float *out_feat, const float *row_dot,
+                                 float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------- GE-SpMM / SDDMM / permute ---- */
 

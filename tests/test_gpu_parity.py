@@ -194,7 +194,7 @@ def test_gat_forward_tb_rejects_a_malformed_tile_list(nat):
     for tile in (32, 64, 7):
         tiles = np.array([(r, t) for r in range(g["n"]) for t in range((deg[r] + tile - 1) // tile)], np.int32)
         assert torch.equal(nat["gat"].make_tile_scheduler(G["row_ptr"], tile).cpu(), torch.from_numpy(tiles))
-        out, emax, esum = nat["gat"].gat_forward_tb(*args, dev(tiles))
+        out, emax, esum = nat["gat"].gat_forward_tb(*args, dev(tiles), tile=tile)
         assert torch.equal(out, ref[0]) and torch.equal(emax, ref[1]) and torch.equal(esum, ref[2])
     good = np.array([(r, t) for r in range(g["n"]) for t in range((deg[r] + 31) // 32)], np.int32)
 
@@ -215,6 +215,9 @@ def test_gat_forward_tb_rejects_a_malformed_tile_list(nat):
         "rows out of order": edit(lambda t: t[::-1]),
         "tile past the end of its row": edit(lambda t: np.vstack([t[:first65 + 3], [[row65, 3]], t[first65 + 3:]])),
         "tile of an empty row": edit(lambda t: np.vstack([[[0, 0]], t])),
+        "last tile of a row missing": edit(lambda t: np.delete(t, first65 + 2, axis=0)),
+        "a list for another tile size": dev(np.array([(r, t) for r in range(g["n"]) for t in range((deg[r] + 63) // 64)],
+                                                     np.int32)),
         "empty list for a non-empty graph": dev(np.zeros((0, 2), np.int32)),
     }
     for what, ts in bad_lists.items():
@@ -791,6 +794,34 @@ def test_gaussian_backward_streaming_and_block_kernels(nat, k, d, edges):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("group", [16, 64, 512])
+def test_gat_seeded_dev_reads_the_pair_from_device_memory(nat):
+    """dgnn_gat_*_seeded_dev: {seed, offset} as a device tensor (what a captured launch needs)
+    gives the bits of the by-value seeded entry points for the same pair, and follows the tensor
+    when it changes between two launches with otherwise identical arguments."""
+    g = GRAPHS["rmat4k"]
+    h, f, p = 4, 64, 0.5
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
+    G = gdev(g)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    seed, off = 123456789012345, 7
+    want = nat["gat"].gat_forward_seeded(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, seed, off)
+    state = torch.tensor([seed, off], dtype=torch.int64, device=DEV)
+    got = nat["gat"].gat_forward_seeded_dev(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, state)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    bw = nat["gat"].gat_backward_seeded(0.2, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                        want[1], want[2], seed, off, x, ar, ac, go, out_feat=want[0])
+    bg = nat["gat"].gat_backward_seeded_dev(0.2, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                            got[1], got[2], state, x, ar, ac, go, out_feat=got[0])
+    assert all(torch.equal(a, b) for a, b in zip(bg, bw))
+    state[1] += 1                                           # same arguments, other contents
+    got2 = nat["gat"].gat_forward_seeded_dev(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, state)
+    want2 = nat["gat"].gat_forward_seeded(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, seed, off + 1)
+    assert torch.equal(got2[0], want2[0]) and not torch.equal(got2[0], got[0])
+    import dgnn_amd
+    with pytest.raises(dgnn_amd.DgnnError):
+        nat["gat"].gat_forward_seeded_dev(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, state.cpu())
+
+
 @pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
 def test_gat_forward_is_independent_of_the_group_size(nat, name, group, monkeypatch):
     """The forward picks its neighbour-group size from the edge count (16 edges per wave on
