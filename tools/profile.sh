@@ -21,4 +21,7 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write
 if [ "${DGNN_PROFILE_TCC:-1}" = "1" ]; then
   timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/tcc -- "${short[@]}" > $out/tcc.log 2>&1 || exit 1
 fi
+if [ "${DGNN_PROFILE_SQ:-0}" = "1" ]; then
+  timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $out/sq -- "${short[@]}" > $out/sq.log 2>&1 || exit 1
+fi
 tail -1 $out/trace.log | cut -c1-700

@@ -54,3 +54,16 @@ if tcc:
         if h + m > 1e6:
             print(f"L2 hit {h / max(h + m, 1):6.3f}  {k[:70]}")
     csv.writer(open(os.path.join(root, "profiles", f"{tag}_pmc_l2_hit_{name}.csv"), "w")).writerows(rows)
+
+sq = per_kernel("sq")
+if sq:
+    names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_WAVES"]
+    rows = [["kernel", "dispatches"] + [f"avg_{c}" for c in names]]
+    kernels = sorted({k for c in sq.values() for k in c})
+    for k in kernels:
+        vals = [sum(sq.get(c, {}).get(k, [0])) / max(len(sq.get(c, {}).get(k, [0])), 1) for c in names]
+        rows.append([k, len(sq.get(names[0], {}).get(k, []))] + [f"{v:.0f}" for v in vals])
+        if vals[0] > 1e7:
+            print(f"SQ wave-instructions  VALU {vals[0]:.3e}  SALU {vals[1]:.3e}  LDS {vals[2]:.3e}  SMEM {vals[3]:.3e}  "
+                  f"VMEM_RD {vals[4]:.3e}  waves {vals[5]:.0f}  {k[:60]}")
+    csv.writer(open(os.path.join(root, "profiles", f"{tag}_pmc_sq_{name}.csv"), "w")).writerows(rows)
