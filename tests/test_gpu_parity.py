@@ -792,8 +792,6 @@ def test_gaussian_backward_streaming_and_block_kernels(nat, k, d, edges):
     assert torch.equal(po, po2) and torch.equal(mo, mo2) and torch.equal(so, so2), "fixed-order sums"
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("group", [16, 64, 512])
 def test_gat_seeded_dev_reads_the_pair_from_device_memory(nat):
     """dgnn_gat_*_seeded_dev: {seed, offset} as a device tensor (what a captured launch needs)
     gives the bits of the by-value seeded entry points for the same pair, and follows the tensor
@@ -822,6 +820,8 @@ def test_gat_seeded_dev_reads_the_pair_from_device_memory(nat):
         nat["gat"].gat_forward_seeded_dev(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, state.cpu())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [16, 64, 512])
 @pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
 def test_gat_forward_is_independent_of_the_group_size(nat, name, group, monkeypatch):
     """The forward picks its neighbour-group size from the edge count (16 edges per wave on

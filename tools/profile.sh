@@ -12,7 +12,9 @@ if [ $# -eq 0 ]; then
   long=(python3 $root/bench.py --workload $name --steps 5 --warmup 2 --no-cpu-baseline)
   short=(python3 $root/bench.py --workload $name --steps 2 --warmup 1 --no-cpu-baseline)
 else
-  long=(python3 "$@"); short=(python3 "$@")
+  prog=$1; shift
+  case $prog in /*) ;; *) prog=$root/$prog ;; esac      # the passes run from /tmp
+  long=(python3 $prog "$@"); short=(python3 $prog "$@")
 fi
 export TMPDIR=/tmp; cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- "${long[@]}" > $out/trace.log 2>&1 || exit 1
