@@ -111,7 +111,40 @@ def knn_case(name, batch, points, dim, k, seed, quantised):
     np.savez_compressed(os.path.join(HERE, f"knn_{name}.npz"), x=x, k=k, src_ind=out.reshape(-1))
 
 
+def layer_grad_pattern(shape):
+    """Deterministic upstream gradient of the layer fixture (not stored: 2.8 MB of noise)."""
+    i = np.arange(int(np.prod(shape)), dtype=np.float64)
+    return (0.5 * np.sin(0.37 * i + 1.3)).astype(np.float32).reshape(shape)
+
+
+def layer_case(name, n, n_edges, in_feats, heads, out_feats, seed):
+    """One forward + backward of the GATConv LAYER (dgNN/layers/gatconv_layer.py:69-92: projection,
+    score terms, fused operator, bias, ELU) at the Cora shape: parameters + input -> output and
+    every gradient, from the float64 restatement tests/layer_ref.py.  Stored as float32 (6e-8
+    relative: far inside the 1e-5 band they are compared at)."""
+    import layer_ref
+    from util import random_graph
+    g = random_graph(n, n_edges, seed)
+    rng = np.random.default_rng(seed)
+    hf = heads * out_feats
+    params = {"W": (rng.standard_normal((in_feats, hf)) * np.sqrt(2.0 * 2 / (in_feats + hf))).astype(np.float32),
+              "attn_l": (rng.standard_normal((1, heads, out_feats)) * np.sqrt(2.0 * 2 / (heads * out_feats + out_feats))).astype(np.float32),
+              "attn_r": (rng.standard_normal((1, heads, out_feats)) * np.sqrt(2.0 * 2 / (heads * out_feats + out_feats))).astype(np.float32),
+              "bias": (0.1 * rng.standard_normal(hf)).astype(np.float32)}
+    feat = rng.standard_normal((n, in_feats)).astype(np.float32)
+    grad = layer_grad_pattern((n, heads, out_feats))
+    vals, _ = layer_ref.gat_layer_f64(params, g, feat, grad, heads, out_feats, activation="elu")
+    np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), heads=heads, out_feats=out_feats, feat=feat,
+                        **{"param_" + k: v for k, v in params.items()},
+                        out=vals["out"].astype(np.float32), grad_feat=vals["feat"].astype(np.float32),
+                        **{"grad_" + k: vals[k].astype(np.float32) for k in params},
+                        **{k: g[k] for k in IDX})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["layer"]:
+        layer_case("gat_cora", 2708, 10556, 64, 4, 64, 21)
+        sys.exit(0)
     gat_case("hub_h1f64", powerlaw_graph(256, 8, hub_degree=200), 1, 64, 0.0, 8)
     gat_case("deg64_h1f100", degree_graph(80, [64, 65, 32, 33, 0, 1] + [3] * 74, 9), 1, 100, 0.0, 9)
     sddmm_spmm_case("deg_h3f6", degree_graph(40, [0, 1, 31, 32, 33, 40, 5, 0] + [2] * 32, 2), 3, 6, 10)
@@ -128,4 +161,5 @@ if __name__ == "__main__":
     gmm_case("deg_k3d2f8", degree_graph(40, [0, 1, 31, 32, 33, 40, 5, 0] + [2] * 32, 2), 3, 2, 8, 5)
     edge_case("k20", 48, 12, 20, 6)
     edge_case("k40", 48, 5, 40, 7)
+    layer_case("gat_cora", 2708, 10556, 64, 4, 64, 21)
     print(sorted(os.listdir(HERE)))

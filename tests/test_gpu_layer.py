@@ -6,8 +6,9 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import layer_ref
 import oracle
-from util import assert_close, rmat_graph
+from util import assert_close, random_graph, rmat_graph
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -125,11 +126,60 @@ def test_gat_layer_matches_the_plain_torch_composition(heads, out_feats, residua
     ref = _plain_layer(layer, graph, feat)
     ref.backward(grad)
     want = [ref.detach()] + [p.grad.clone() for p in layer.parameters()] + [feat.grad.clone()]
-    names = ["out"] + [n for n, _ in layer.named_parameters()] + ["feat.grad"]
+    names = ["out"] + [n for n, _ in layer.named_parameters()] + ["feat"]
+    # both ways of writing the layer sit in the parity band around the float64 restatement of the
+    # reference layer (tests/layer_ref.py), each with the summand mass of its reduction chain
+    act_name = {None: None, F.elu: "elu", F.relu: "relu", torch.tanh: "tanh"}[activation]
+    params = {n_: host(p_) for n_, p_ in layer.named_parameters()}
+    res_kind = None if not residual else ("identity" if isinstance(layer.res_fc, torch.nn.Identity) else "linear")
+    vals, masses = layer_ref.gat_layer_f64(params, g, host(feat), host(grad), heads, out_feats, activation=act_name,
+                                           residual=res_kind)
     for nm, a, b in zip(names, got, want):
-        scale = float(b.abs().max()) + 1e-6
-        assert float((a - b).abs().max()) <= 2e-4 * scale, (nm, float((a - b).abs().max()), scale)
+        ref64 = vals[nm].reshape(a.shape)
+        mass = masses[nm].reshape(a.shape)
+        assert_close(host(a), ref64, f"GATConv layer: {nm}", mass=mass)
+        assert_close(host(b), ref64, f"GATConv layer written with torch ops: {nm}", mass=mass)
     layer.eval()
     with torch.no_grad():
         ev = layer(*graph, feat)
     assert torch.allclose(ev, got[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,d,out_feats,residual,bias", [(3, 2, 64, False, True), (2, 3, 16, True, True),
+                                                       (3, 2, 41, True, False), (1, 1, 8, False, False)])
+def test_gmm_layer_against_the_float64_reference(k, d, out_feats, residual, bias):
+    """GMMConv layer (dgNN/layers/gmmconv_layer.py:9-65): state_dict keys, initialisation recipe
+    (mu ~ N(0, 0.1), inv_sigma = 1, zero bias: :43-51), forward and every gradient against the
+    float64 restatement of the reference layer."""
+    from dgnn_amd.layers import GMMConv
+    g = random_graph(1200, 9000, 3)
+    graph = [dev(g[key]) for key in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")]
+    torch.manual_seed(5)
+    in_feats = 24
+    layer = GMMConv(in_feats, out_feats, d, k, residual=residual, bias=bias).to(DEV)
+    want_keys = ["mu", "inv_sigma", "fc.weight"] + (["bias"] if bias else []) + (["res_fc.weight"] if residual else [])
+    assert sorted(layer.state_dict()) == sorted(want_keys)
+    assert layer.fc.weight.shape == (k * out_feats, in_feats) and layer.mu.shape == (k, d)
+    assert bool((layer.inv_sigma == 1).all()) and (not bias or bool((layer.bias == 0).all()))
+    assert 0.03 < float(layer.mu.std()) < 0.3 or k * d < 4
+    # a state_dict with the reference's keys and shapes loads (checkpoint compatibility)
+    ref_state = {key: torch.randn_like(v) for key, v in layer.state_dict().items()}
+    layer.load_state_dict(ref_state)
+    with torch.no_grad():
+        layer.inv_sigma.copy_(1 + 0.1 * torch.randn_like(layer.inv_sigma))
+        layer.mu.mul_(0.1)
+        layer.fc.weight.mul_(0.2)
+    feat = torch.randn((g["n"], in_feats), device=DEV, requires_grad=True)
+    pseudo = torch.rand((g["nnz"], d), device=DEV, requires_grad=True)
+    grad = torch.randn((g["n"], out_feats), device=DEV)
+    out = layer(*graph, feat, pseudo)
+    assert out.shape == (g["n"], out_feats)
+    out.backward(grad)
+    params = {n_: host(p_) for n_, p_ in layer.named_parameters()}
+    vals, masses = layer_ref.gmm_layer_f64(params, g, host(feat), host(pseudo), host(grad), k, out_feats,
+                                           residual="linear" if residual else None)
+    assert_close(host(out), vals["out"], "GMMConv layer: out", mass=masses["out"])
+    assert_close(host(feat.grad), vals["feat"], "GMMConv layer: feat.grad", mass=masses["feat"])
+    assert_close(host(pseudo.grad), vals["pseudo"], "GMMConv layer: pseudo.grad", mass=masses["pseudo"])
+    for n_, p_ in layer.named_parameters():
+        assert_close(host(p_.grad), vals[n_], f"GMMConv layer: {n_}.grad", mass=masses[n_])

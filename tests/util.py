@@ -197,6 +197,20 @@ def gat_masses_torch(row_ptr, col_ind, attn_row, attn_col, in_feat, grad, slope,
     return tuple(t.cpu().numpy() for t in (m_out, m_gf, m_gr, m_gc))
 
 
+def gaussian_bp_masses(pseudo, mu, inv_sigma, gg_abs):
+    """sum|terms| of the Gaussian gradients (analytic gradient of exp(-0.5 sum_d ((p-mu) s)^2)
+    times grad_gauss): -> (m_pseudo [E,D], m_mu [K,D], m_inv_sigma [K,D]); gg_abs = |grad_gauss|
+    (or its own mass when it is itself a reduction)."""
+    p = np.asarray(pseudo, np.float64)[:, None, :]
+    m = np.asarray(mu, np.float64)[None]
+    s = np.asarray(inv_sigma, np.float64)[None]
+    diff = p - m
+    gauss = np.exp(-0.5 * ((diff * s) ** 2).sum(-1))
+    base = np.asarray(gg_abs, np.float64)[:, :, None] * gauss[:, :, None]
+    lin = base * np.abs(diff) * s * s
+    return lin.sum(1), lin.sum(0), (base * diff * diff * np.abs(s)).sum(0)
+
+
 def gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p=0.0):
     """sum|terms| of every reduction of the fused GAT forward/backward, in float64 (numpy):
     out_feat, grad_feat, grad_attn_row, grad_attn_col.  Upper bounds (dropout keeps all)."""
