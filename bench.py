@@ -73,24 +73,28 @@ def rmat_edges(n, target, scale, device, seed, abcd=(0.57, 0.19, 0.19, 0.05)):
     return keys
 
 
-def build_graph(name, device, seed=0):
-    """CSR by destination / CSC / permute in the reference's convention
-    (script/train/train_gatconv.py:78-94), built on the device."""
-    import dgnn_amd
+def graph_from_keys(keys, n, device):
+    """Sorted unique int64 keys dst*n+src -> CSR by destination / CSC / permute in the reference's
+    convention (script/train/train_gatconv.py:78-94), built on the device."""
+    import dgnn_amd  # noqa: F401
     from dgnn_amd.native import format_conversion
-    n, target, scale = WORKLOADS[name]
-    keys = rmat_edges(n, target, scale, device, seed)
     dst = keys // n
     col_ind = (keys % n).to(torch.int32)
     counts = torch.bincount(dst, minlength=n)
     row_ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(counts, 0)
     row_ptr = row_ptr.to(torch.int32)
-    del keys, dst, counts
+    del dst, counts
     col_ptr, row_ind, permute = format_conversion.csr2csc_int(row_ptr, col_ind)
     torch.cuda.synchronize()
     return dict(n=n, nnz=int(col_ind.numel()), row_ptr=row_ptr, col_ind=col_ind, col_ptr=col_ptr,
                 row_ind=row_ind, permute=permute)
+
+
+def build_graph(name, device, seed=0):
+    n, target, scale = WORKLOADS[name]
+    keys = rmat_edges(n, target, scale, device, seed)
+    return graph_from_keys(keys, n, device)
 
 
 def algorithmic_bytes(n, nnz, h, f):

@@ -50,9 +50,11 @@ def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, 
             raise DgnnError("attn_drop > 0 under HIP-graph capture: this shape is outside the seeded kernels "
                             "(heads > 8 or misaligned rows); capture without dropout or run it eagerly")
         return res[0], res[1], res[2], None, mine
-    if in_feat.device not in _CAPTURE_RNG:
-        init_capture_rng(in_feat.device)
     seed = int(torch.randint(0, 1 << 62, (1,)).item())
+    if in_feat.device not in _CAPTURE_RNG:
+        # derived from this call's seed: no extra draw from torch's generator (the sequence of
+        # eager seeds under torch.manual_seed stays what it was)
+        init_capture_rng(in_feat.device, seed=seed ^ 0x2545F4914F6CDD1D)
     res = fused_gat.gat_forward_seeded(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, seed)
     if res is not None:
         return res[0], res[1], res[2], None, seed

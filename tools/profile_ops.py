@@ -5,7 +5,9 @@ tools/profile_ops.py <name>): a few launches of ONE operator family at its BASEL
   edgeconv                  fused EdgeConv fwd / bwd (atomic + deterministic) + k-NN, 32 x 2048, k = 20,
                             the four DGCNN widths
   sddmm_spmm                mhsddmm + spmm_csr on the Reddit shape, 4 x 64
-  gat_1x64_products / gat_8x8_products / gat_1x64_reddit   narrow fused GAT fwd + bwd"""
+  gat_1x64_products / gat_8x8_products / gat_1x64_reddit   narrow fused GAT fwd + bwd
+  layer_products            whole GATConv layer (in = 100, 4 x 64, ELU, bias) fwd + bwd and an eval forward:
+                            what the score / epilogue kernels around the operator cost"""
 import os
 import sys
 
@@ -84,6 +86,24 @@ def gat(H, F, workload):
                         emask, x, ar, ac, go, out_feat=out)
 
 
+def layer(workload):
+    import torch.nn.functional as F
+    from dgnn_amd.layers import GATConv
+    g = bench.build_graph(workload, dev)
+    graph = [g[k] for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")]
+    torch.manual_seed(0)
+    lay = GATConv(100, 64, 4, activation=F.elu).to(dev)
+    feat = torch.randn((g["n"], 100), device=dev, requires_grad=True)
+    go = torch.randn((g["n"], 4, 64), device=dev)
+    for _ in range(REPS):
+        lay.zero_grad(); feat.grad = None
+        lay.train()
+        lay(*graph, feat).backward(go)
+        lay.eval()
+        with torch.no_grad():
+            lay(*graph, feat)
+
+
 if __name__ == "__main__":
     w = sys.argv[1]
     if w.startswith("gmm_"):
@@ -92,6 +112,8 @@ if __name__ == "__main__":
         edgeconv()
     elif w == "sddmm_spmm":
         sddmm_spmm()
+    elif w.startswith("layer_"):
+        layer(w[6:])
     elif w.startswith("gat_"):
         _, hf, wl = w.split("_")
         h, f = hf.split("x")
