@@ -91,9 +91,19 @@ def graph_from_keys(keys, n, device):
                 row_ind=row_ind, permute=permute)
 
 
-def build_graph(name, device, seed=0):
+def build_graph(name, device, seed=0, labels="natural"):
+    """labels: "natural" = the R-MAT generator's ids (hubs at the ids with few set bits);
+    "scrambled" = the same graph after dgnn_amd.graph.relabel_nodes(how="scramble"), the load-time
+    vertex scrambling Graph500 prescribes for R-MAT (real datasets carry no such id structure)."""
     n, target, scale = WORKLOADS[name]
     keys = rmat_edges(n, target, scale, device, seed)
+    if labels == "scrambled":
+        from dgnn_amd.graph import relabel_nodes
+        src, dst, _ = relabel_nodes(keys % n, keys // n, n, how="scramble", seed=seed)
+        keys = torch.sort(dst * n + src).values
+        del src, dst
+    elif labels != "natural":
+        raise ValueError(labels)
     return graph_from_keys(keys, n, device)
 
 
@@ -211,6 +221,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="products", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--labels", default="scrambled", choices=["scrambled", "natural"],
+                    help="node ids of the R-MAT graph: scrambled = after the load-time relabelling of "
+                         "dgnn_amd.graph.relabel_nodes (Graph500-style; the default), natural = the generator's ids; "
+                         "the single-GPU line reports the other labelling too")
     ap.add_argument("--attn-drop", type=float, default=0.0,
                     help="secondary run (test/gat_result.sh:10 uses 0.5); the headline is 0")
     ap.add_argument("--force-dist", action="store_true",
@@ -249,7 +263,7 @@ def main():
     if use_pg:
         # one graph for everybody: rank 0 builds it, the index arrays are broadcast over RCCL
         import torch.distributed as dist
-        g = build_graph(args.workload, device, seed=0) if rank == 0 else None
+        g = build_graph(args.workload, device, seed=0, labels=args.labels) if rank == 0 else None
         meta = torch.tensor([g["n"], g["nnz"]] if rank == 0 else [0, 0], dtype=torch.int64, device=device)
         dist.broadcast(meta, src=0)
         n, nnz = int(meta[0]), int(meta[1])
@@ -263,7 +277,7 @@ def main():
         for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute"):
             dist.broadcast(g[k], src=0)
     else:
-        g = build_graph(args.workload, device, seed=0)
+        g = build_graph(args.workload, device, seed=0, labels=args.labels)
     n, nnz = g["n"], g["nnz"]
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
@@ -412,7 +426,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
-                                   f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd",
+                                   f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd, node labels {args.labels}"
+                                   + (" (load-time relabelling, dgnn_amd.graph.relabel_nodes)" if args.labels == "scrambled" else ""),
                        "parallelism": "single GPU" if world == 1 else
                        f"row-partition x{world}, RCCL {os.environ.get('DGNN_DIST_MODE', 'halo')} exchange of boundary rows"
                        + (f", {runner.chunks} pipelined chunks" if runner.mode == "halo" else "")},
@@ -423,6 +438,24 @@ def main():
             line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
                                  f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")
             line["value"] = runner.nnz_fwd / (ms_per_step * 1e-3)
+        if world == 1 and not use_pg and not args.force_dist and not args.simulate_rank and args.workload != "cora":
+            # the same step on the other labelling of the same graph (continuity with round 1,
+            # which ran on the generator's ids)
+            other = "natural" if args.labels == "scrambled" else "scrambled"
+            del g
+            torch.cuda.empty_cache()
+            g = build_graph(args.workload, device, seed=0, labels=other)
+            for _ in range(2):
+                step_fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k_other = max(3, min(args.steps, 10))
+            for _ in range(k_other):
+                step_fn()
+            torch.cuda.synchronize()
+            ms_other = (time.perf_counter() - t0) / k_other * 1e3
+            line["other_labels"] = {"labels": other, "ms_per_step": round(ms_other, 3), "steps": k_other,
+                                    "value": nnz / (ms_other * 1e-3)}
         if not args.no_cpu_baseline and world == 1 and not args.simulate_rank:      # a reported baseline of the N = 1 run only
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)

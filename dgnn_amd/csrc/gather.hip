@@ -91,6 +91,8 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   // rows narrower than one wave of float4 slots are bound by instructions per edge, not bandwidth
   // (the STEADY instantiation of the kernel; DGNN_FWD_STEADY=0 switches it off for A/B runs)
   P.steady = (vec4 && P.rowv < DGNN_WAVE && env_int("DGNN_FWD_STEADY", 1) != 0) ? 1 : 0;
+  // rows of at most 32 float4 slots: several edges per load step (DGNN_FWD_PACK=0: A/B runs)
+  P.pack_s = (P.steady && env_int("DGNN_FWD_PACK", 1) != 0) ? fast_pack_lanes(P.rowv, vec4) : 0;
   {
     long long g = ((long long)P.m + 255) / 256;
     if (g > 8192) g = 8192;
@@ -99,7 +101,7 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   }
   if (P.T == 0) return DGNN_OK;
   // DGNN_FWD_LDS_PAD: extra dynamic LDS per workgroup = an occupancy limiter for tuning runs
-  const size_t lds = fast_lds_bytes(P.H, P.L) + (size_t)env_int("DGNN_FWD_LDS_PAD", 0);
+  const size_t lds = fast_lds_bytes(P.H, P.L, P.pack_s > 0) + (size_t)env_int("DGNN_FWD_LDS_PAD", 0);
   const dim3 grid(blocks_for_waves(P.T));
   if (MODE == MODE_GAT) timer_mark(0, 0, st);
   // vector slots per lane: one walk over the edges for rows up to 64 / 128 / 256 slots

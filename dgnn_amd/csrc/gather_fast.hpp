@@ -44,6 +44,8 @@ struct GatherParams {
   int slot_stride;                   // floats per partial slot (HF + 2H rounded up to 4)
   int dim;                           // GMM pseudo dimension
   int steady;                        // narrow rows: unguarded steady-state gather loop (phase C)
+  int pack_s;                        // > 0: lanes per row of the PACKED gather (rows of <= 32 float4 slots:
+                                     // 64 / pack_s edges of a row per load instruction), see phase C
   float attn_drop, slope;
   const int *row_ptr, *col_ind;
   const float *attn_row, *attn_col;  // GAT
@@ -84,10 +86,22 @@ static inline int fast_group_size(int H, int nnz, bool narrow = false) {
   // latencies: its rows' softmax passes, then its edges four at a time)
   return shrink_group_for_small_graphs(dflt, nnz, 16);
 }
-static inline size_t fast_lds_bytes(int H, int L) {
-  // per wave: weights [L*H] + column ids [L] + flush queue [L]
-  return (size_t)DGNN_WAVES_PER_BLOCK * (size_t)L * (H + 2) * sizeof(float);
+__host__ __device__ static inline size_t fast_wave_lds_floats(int H, int L, bool packed) {
+  // per wave: weights [L*H] + column ids [L] + flush queue [L] (+ packed gather: step list, 16 bit x L)
+  return (size_t)L * (H + 2) + (packed ? (size_t)L / 2 : 0);
 }
+static inline size_t fast_lds_bytes(int H, int L, bool packed = false) {
+  return (size_t)DGNN_WAVES_PER_BLOCK * fast_wave_lds_floats(H, L, packed) * sizeof(float);
+}
+// Packed gather (rows of at most 32 float4 slots): lanes per row = the power of two covering the
+// row's slots, at least 4 (so at most 16 edges share one load instruction); 0 = not applicable.
+static inline int fast_pack_lanes(int rowv, bool vec4) {
+  if (!vec4 || rowv > 32) return 0;
+  int s = 4;
+  while (s < rowv) s <<= 1;
+  return s;
+}
+#define DGNN_PACK_END 0x4000u      // step list entry: last step of its row segment
 
 // Row bookkeeping: empty rows are finished here (out = 0, edge_max = -1e38, edge_sum = 0:
 // fused_gatconv_kernel.cu:45,66,90) and every group learns the row its first edge belongs to.
@@ -184,9 +198,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   if (t >= P.T) return;
   if (MODE == MODE_GAT) drop_resolve(P.rng);
   const int L = P.L, H = P.H;
-  float *sc = lds_raw + (size_t)wib * L * (H + 2);        // [L][H] score terms -> weights
+  const bool packed = STEADY && P.pack_s > 0;
+  float *sc = lds_raw + (size_t)wib * fast_wave_lds_floats(H, L, packed);   // [L][H] score terms -> weights
   unsigned *cidx = (unsigned *)(sc + (size_t)L * H);      // [L] column id | ROWEND
   int *dq = (int *)(cidx + L);                            // [L] flush destinations, in row order
+  // packed gather: the group's load steps, one per (up to) G = 64 / pack_s consecutive edges of ONE
+  // row: first edge (10 bits) | edges - 1 (4 bits) | DGNN_PACK_END
+  unsigned short *steps = (unsigned short *)(dq + L);
+  int nsteps = 0;
 
   const int e0 = t * L;
   const int e1 = min(e0 + L, P.nnz);
@@ -394,6 +413,18 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           dq[nflush] = whole ? r : -(slot + 1);
         }
         ++nflush;
+        if constexpr (STEADY) {
+          if (packed) {
+            const int G = DGNN_WAVE / P.pack_s;
+            const int ns = (b - a + G - 1) / G;
+            for (int j = lane; j < ns; j += DGNN_WAVE) {
+              const int p0 = a + j * G;
+              steps[nsteps + j] = (unsigned short)((unsigned)p0 | ((unsigned)(min(G, b - p0) - 1) << 10) |
+                                                   (j == ns - 1 ? DGNN_PACK_END : 0u));
+            }
+            nsteps += ns;
+          }
+        }
       }
       if (re >= e1 || r + 1 >= P.m) break;   // second test: never walk past the last row
       rs = re;
@@ -401,6 +432,90 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     }
   }
   wave_lds_sync();
+
+  // ---------------------------------------------------------------- phase C, packed (narrow rows)
+  // A row of S <= 32 float4 slots leaves 64 - S lanes of a one-edge-per-step walk idle and the
+  // walk bound by instructions per EDGE (~30 VALU + ~20 SALU, profiles/r2a_pmc_sq_gat_1x64_*).
+  // Here the wave's lanes form G = 64 / S groups; one step loads G consecutive edges of ONE row
+  // (group g: edge p0 + g, lane s of the group: slot s), every group keeps its own partial sum,
+  // and at the row's last step the G partials are added across groups (xor shuffles) and stored.
+  // Steps never span rows (the step list is built in phase B), so no lane ever mixes rows; idle
+  // groups of a row's last step re-read the step's first edge with weight 0.
+  if constexpr (STEADY && NS == 1 && VEC == 4) {
+    if (packed) {
+      const int S = P.pack_s;
+      const int g = lane / S, sl = lane % S;
+      const bool active = sl < P.rowv;
+      const int head = active ? (sl * 4) / P.F : 0;
+      const size_t lane_off = (size_t)(active ? sl : 0) * 4;
+      const float *wbase = sc + head;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 ring[DGNN_FAST_U];
+      float wring[DGNN_FAST_U];
+      int q = 0;
+      auto issue = [&](int j, float4 &x, float &w) {
+        const unsigned it = (unsigned)uniform_i32((int)steps[j]);
+        const int p0 = (int)(it & 1023u), n = (int)((it >> 10) & 15u) + 1;
+        const bool live = g < n;
+        const int pe = p0 + (live ? g : 0);
+        const unsigned c = cidx[pe] & ~DGNN_ROWEND;
+        w = live ? wbase[(size_t)pe * H] : 0.f;
+        x = *(const float4 *)(P.in_feat + (size_t)c * P.HF + lane_off);
+      };
+      auto consume = [&](const float4 &x, float w, int j) {
+        V::fma(acc, w, x);
+        if (uniform_i32((int)steps[j]) & (int)DGNN_PACK_END) {
+          for (int off = S; off < DGNN_WAVE; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
+            acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
+            acc.z += __shfl_xor(acc.z, off, DGNN_WAVE);
+            acc.w += __shfl_xor(acc.w, off, DGNN_WAVE);
+          }
+          const int d = uniform_i32(dq[q]);
+          ++q;
+          float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+          if (active && g == 0) *(float4 *)(dst + lane_off) = acc;
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      int j = 0;
+      if (nsteps >= 2 * DGNN_FAST_U) {
+#pragma unroll
+        for (int k = 0; k < DGNN_FAST_U; ++k) {
+          issue(k, ring[k], wring[k]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; j + 2 * DGNN_FAST_U <= nsteps; j += DGNN_FAST_U) {
+#pragma unroll
+          for (int k = 0; k < DGNN_FAST_U; ++k) {
+            consume(ring[k], wring[k], j + k);
+            issue(j + k + DGNN_FAST_U, ring[k], wring[k]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // the ring holds steps j .. j+U-1; at most U-1 further steps remain
+#pragma unroll
+        for (int k = 0; k < DGNN_FAST_U; ++k) {
+          const float4 x = ring[k];
+          const float w = wring[k];
+          if (j + k + DGNN_FAST_U < nsteps) issue(j + k + DGNN_FAST_U, ring[k], wring[k]);
+          consume(x, w, j + k);
+        }
+        j += DGNN_FAST_U;
+#pragma unroll
+        for (int k = 0; k < DGNN_FAST_U; ++k)
+          if (j + k < nsteps) consume(ring[k], wring[k], j + k);
+      } else {
+        for (; j < nsteps; ++j) {
+          float4 x;
+          float w;
+          issue(j, x, w);
+          consume(x, w, j);
+        }
+      }
+      return;
+    }
+  }
 
   // ---------------------------------------------------------------- phase C: pipelined gather
   const int span = DGNN_WAVE * NS;

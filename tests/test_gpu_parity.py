@@ -93,13 +93,15 @@ def test_gat_forward_backward(nat, name, h, f, p):
 
 @pytest.mark.parametrize("name", ["deg_edges", "powerlaw256", "rmat4k"])
 @pytest.mark.parametrize("fwd_l,bwd_l", [(512, 256), (256, 128), (128, 64), (64, 64)])
-def test_gat_every_group_size(nat, name, fwd_l, bwd_l, monkeypatch):
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 64), (4, 16), (1, 16), (8, 8), (2, 24)])
+def test_gat_every_group_size(nat, name, fwd_l, bwd_l, h, f, monkeypatch):
     """The library shrinks its neighbour groups on small graphs; the production sizes of the
-    big graphs (512 forward / 256 backward) are forced here on the small ones."""
+    big graphs (512 forward / 256 backward) are forced here on the small ones, for the headline
+    shape and for narrow rows (the packed gather: 4, 16 or 8 edges of a row per load step)."""
     monkeypatch.setenv("DGNN_FWD_L", str(fwd_l))
     monkeypatch.setenv("DGNN_BWD_L", str(bwd_l))
     g = GRAPHS[name]
-    h, f, slope = 4, 64, 0.2
+    slope = 0.2
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=13)
     G = gdev(g)
     d_in, d_ar, d_ac, d_grad = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
@@ -340,6 +342,36 @@ def test_prepare_graph_matches_the_reference_scipy_recipe(self_loops):
         assert g_arr.dtype == np.int32 and np.array_equal(g_arr, w_arr.astype(np.int32)), nm
     with pytest.raises(ValueError):
         prepare_graph(dev(src), dev(dst), n - 1, self_loops)
+
+
+@pytest.mark.parametrize("how", ["scramble", "degree"])
+def test_relabelled_graph_gives_the_same_results_up_to_the_permutation(nat, how):
+    """dgnn_amd.graph.relabel_nodes (load-time relabelling for the memory system): the operator on
+    the relabelled graph with permuted inputs returns the permuted results of the oracle on the
+    original graph -- forward and every gradient."""
+    from dgnn_amd.graph import permute_rows, prepare_graph, relabel_nodes, unpermute_rows
+    g = GRAPHS["rmat4k"]
+    h, f = 4, 64
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=17)
+    dst = np.repeat(np.arange(g["n"]), np.diff(g["row_ptr"]))
+    nsrc, ndst, new_of_old = relabel_nodes(dev(g["col_ind"].astype(np.int64)), dev(dst.astype(np.int64)), g["n"], how=how, seed=3)
+    assert sorted(host(new_of_old).tolist()) == list(range(g["n"]))          # a permutation
+    if how == "degree":
+        deg = np.bincount(dst, minlength=g["n"]) + np.bincount(g["col_ind"], minlength=g["n"])
+        assert (np.diff(deg[np.argsort(host(new_of_old))]) <= 0).all()       # new id order = descending degree
+    G = prepare_graph(nsrc, ndst, g["n"], self_loops="keep")
+    x, ar, ac, go = (permute_rows(dev(t), new_of_old) for t in (in_feat, attn_row, attn_col, grad))
+    out, emax, esum, emask = nat["gat"].gat_forward(ar, ac, G[0], G[1], 0.2, x, 0.0)
+    gf, gr, gc = nat["gat"].gat_backward(0.2, 0.0, *G, emax, esum, emask, x, ar, ac, go, out_feat=out)
+    o64, m64, s64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0, None)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, 0.0, g["row_ptr"], g["col_ind"], None, in_feat, attn_row, attn_col, grad)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2)
+    assert_close(host(unpermute_rows(out, new_of_old)), o64, f"relabelled ({how}): out_feat", mass=m_out)
+    assert_close(host(unpermute_rows(gf, new_of_old)), gf64, f"relabelled ({how}): grad_feat", mass=m_gf)
+    assert_close(host(unpermute_rows(gr, new_of_old)), gr64, f"relabelled ({how}): grad_attn_row", mass=m_gr)
+    assert_close(host(unpermute_rows(gc, new_of_old)), gc64, f"relabelled ({how}): grad_attn_col", mass=m_gc)
+    assert np.array_equal(host(unpermute_rows(emax, new_of_old)), oracle.gat_forward(
+        attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0, None)[1]), "edge_max stays bit-exact"
 
 
 @pytest.mark.parametrize("name", list(GRAPHS))
