@@ -32,6 +32,8 @@ namespace dgnn {
 struct BwdParams {
   int n, m, nnz, H, F, HF, L, T;
   int steady;          // narrow rows: unguarded steady-state gather stream (STEADY instantiation)
+  int pack_s;          // > 0: lanes per row of the PACKED stream (H * fv <= 32 lanes: 64 / pack_s edges of a
+                       // column per load step), see the stream phase
   int vec;             // floats per lane load: 4 (F % 4 == 0, 16-byte aligned rows) or 1
   int fv;              // lanes per head: power of two >= ceil(F/vec), <= 64
   int hpp;             // heads per lane pass = 64 / fv; ceil(H / hpp) passes walk the stream
@@ -198,6 +200,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
 
   // ---------------------------------------------------------------- columns of the group
   int K = 0;   // non-empty columns seen so far
+  const bool packed = STEADY && P.pack_s > 0;
+  // packed stream: the load steps of the group in `stream`: per column one U step (the column's
+  // own row: column id | UFLAG) followed by one step per (up to) G = 64 / pack_s consecutive
+  // entries of that column: first entry (10 bits) | entries - 1 (4 bits) | DGNN_PACK_END on the
+  // column's last step.  Steps never span columns.
+  int nsteps = 0;
   {
     int cbase = uniform_i32(P.task_col0[t]);
     while (true) {
@@ -217,8 +225,27 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         const int slot = (lo < e0) ? 2 * t : 2 * t + 1;
         colk[k] = c;
         dq[k] = whole ? c : -(slot + 1);
-        stream[a + k] = (unsigned)c | DGNN_BWD_UFLAG;
+        if (!packed) stream[a + k] = (unsigned)c | DGNN_BWD_UFLAG;
         for (int p = a; p < b; ++p) kof[p] = (unsigned)k | (p == b - 1 ? DGNN_BWD_END : 0u);
+      }
+      if constexpr (STEADY) {
+        if (packed) {
+          const int G = DGNN_WAVE / P.pack_s;
+          const int mine = nonempty ? 1 + (b - a + G - 1) / G : 0;
+          int incl = mine;                                  // inclusive prefix sum over the lanes
+#pragma unroll
+          for (int off = 1; off < DGNN_WAVE; off <<= 1) {
+            const int up = __shfl_up(incl, off, DGNN_WAVE);
+            if (lane >= off) incl += up;
+          }
+          if (nonempty) {
+            int pos = nsteps + incl - mine;
+            stream[pos++] = (unsigned)c | DGNN_BWD_UFLAG;
+            for (int p0 = a; p0 < b; p0 += G)
+              stream[pos++] = (unsigned)p0 | ((unsigned)(min(G, b - p0) - 1) << 10) | (p0 + G >= b ? DGNN_PACK_END : 0u);
+          }
+          nsteps += bcast_i32(incl, DGNN_WAVE - 1);
+        }
       }
       K += __popcll(bal);
       const bool reached_end = (c >= P.n - 1) || (hi >= e1);
@@ -236,7 +263,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       const unsigned kk = kof[p];
       const int k = (int)(kk & DGNN_BWD_IDMASK);
       const int c = colk[k];
-      stream[p + k + 1] = (unsigned)rid[j] | (kk & DGNN_BWD_END);
+      if (packed) kof[p] = (unsigned)rid[j];          // the stream gathers grad[kof[p]]; the ordinal is dead now
+      else stream[p + k + 1] = (unsigned)rid[j] | (kk & DGNN_BWD_END);
       if (BMODE == BWD_GMM) {
         const size_t pos = (size_t)P.permute[e0 + p];
 #pragma unroll
@@ -293,8 +321,107 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     int k = -1;
     vec_t ring[DGNN_FAST_U];
     bool took_steady = false;
+    if constexpr (STEADY && VEC == 4) {
+      if (packed) {
+        // ---- packed stream (H * fv <= 32 lanes per row): the lanes form G = 64 / S groups; an
+        // edge step gathers the grad rows of G consecutive entries of ONE column (group g: entry
+        // p0 + g), each group keeps its own partial sums, and the column's last step adds them
+        // across groups.  The column's own row (U step) is loaded by every group alike.
+        took_steady = true;
+        const int S = P.pack_s;
+        const int g = lane / S, sl = lane % S;
+        const int hd = sl / P.fv, qq = sl % P.fv;
+        const bool act = hd < H && qq * 4 < P.F;
+        const int phead = act ? hd : 0;
+        const size_t poff = act ? (size_t)phead * P.F + (size_t)qq * 4 : 0;
+        const bool pleader = act && qq == 0;
+        auto issue = [&](int j, float4 &x) {
+          const unsigned it = (unsigned)uniform_i32((int)stream[j]);
+          const bool isu = (it & DGNN_BWD_UFLAG) != 0u;
+          const int p0 = isu ? 0 : (int)(it & 1023u), n = isu ? 0 : (int)((it >> 10) & 15u) + 1;
+          const int pe = p0 + (g < n ? g : 0);
+          const unsigned r = isu ? (it & DGNN_BWD_IDMASK) : kof[pe];
+          x = *(const float4 *)((isu ? P.in_feat : P.grad) + (size_t)r * P.HF + poff);
+        };
+        auto consume = [&](const float4 &x, int j) {
+          const unsigned it = (unsigned)uniform_i32((int)stream[j]);
+          if (it & DGNN_BWD_UFLAG) {
+            u = x;
+            ++k;
+            return;
+          }
+          const int p0 = (int)(it & 1023u), n = (int)((it >> 10) & 15u) + 1;
+          const bool live = g < n;
+          const int pe = p0 + (live ? g : 0);
+          float2 *cp = cell + (size_t)pe * HC + phead;
+          const float2 wb = *cp;
+          const float w = live ? fabsf(wb.x) : 0.f;
+          const float slp = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
+          float dot = act ? vec_dot<4>(x, u) : 0.f;
+          dot = group_reduce(dot, P.fv, OpSum());
+          const float d = live ? ((BMODE == BWD_GMM) ? dot : fmaf(slp * w, dot, -wb.y)) : 0.f;
+          V::fma(acc, w, x);
+          dsum += d;
+          if (pleader && live) cp->y = d;
+          if (it & DGNN_PACK_END) {
+            for (int off = S; off < DGNN_WAVE; off <<= 1) {
+              acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
+              acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
+              acc.z += __shfl_xor(acc.z, off, DGNN_WAVE);
+              acc.w += __shfl_xor(acc.w, off, DGNN_WAVE);
+              dsum += __shfl_xor(dsum, off, DGNN_WAVE);
+            }
+            const int dst = uniform_i32(dq[k]);
+            if (g == 0) {
+              if (dst >= 0) {
+                if (act) *(float4 *)(P.grad_feat + (size_t)dst * P.HF + poff) = acc;
+                if (BMODE == BWD_GAT && pleader) P.grad_attn_col[(size_t)dst * H + phead] = dsum;
+              } else {
+                float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
+                if (act) *(float4 *)(sp + poff) = acc;
+                if (BMODE == BWD_GAT && pleader) sp[P.HF + phead] = dsum;
+              }
+            }
+            acc = V::zero();
+            dsum = 0.f;
+          }
+        };
+        int j = 0;
+        if (nsteps >= 2 * DGNN_FAST_U) {
+#pragma unroll
+          for (int i = 0; i < DGNN_FAST_U; ++i) {
+            issue(i, ring[i]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          for (; j + 2 * DGNN_FAST_U <= nsteps; j += DGNN_FAST_U) {
+#pragma unroll
+            for (int i = 0; i < DGNN_FAST_U; ++i) {
+              consume(ring[i], j + i);
+              issue(j + i + DGNN_FAST_U, ring[i]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < DGNN_FAST_U; ++i) {
+            const float4 x = ring[i];
+            if (j + i + DGNN_FAST_U < nsteps) issue(j + i + DGNN_FAST_U, ring[i]);
+            consume(x, j + i);
+          }
+          j += DGNN_FAST_U;
+#pragma unroll
+          for (int i = 0; i < DGNN_FAST_U; ++i)
+            if (j + i < nsteps) consume(ring[i], j + i);
+        } else {
+          for (; j < nsteps; ++j) {
+            float4 x;
+            issue(j, x);
+            consume(x, j);
+          }
+        }
+      }
+    }
     if constexpr (STEADY) {
-      if (P.steady && items >= 2 * DGNN_FAST_U) {
+      if (!took_steady && P.steady && items >= 2 * DGNN_FAST_U) {
         took_steady = true;
         // one item of the stream, its row already in x
         auto consume = [&](const vec_t &x, unsigned v, int it) {

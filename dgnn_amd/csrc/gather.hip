@@ -191,6 +191,15 @@ int bwd_lanes_per_head(int f, int vec) {
   return g;
 }
 int bwd_heads_padded(int h) { return h <= 1 ? 1 : h <= 2 ? 2 : h <= 4 ? 4 : 8; }
+// Packed stream of the backward (gat_bwd_fast.hpp): rows whose lane map covers at most 32 lanes
+// (h heads x fv lanes) -> lanes per row = the power of two covering them, at least 4; 0 = off
+// (DGNN_BWD_PACK=0: A/B runs).  Only the STEADY (narrow, float4) instantiation has it.
+int bwd_pack_lanes(bool steady, int h, int fv) {
+  if (!steady || h * fv > env_int("DGNN_PACK_MAX_S", 16) || env_int("DGNN_BWD_PACK", 1) == 0) return 0;
+  int s = 4;
+  while (s < h * fv) s <<= 1;
+  return s;
+}
 bool bwd_fast_shape(int m, int n, int h, int f) {
   if (force_generic() || h > 8 || m >= (1 << 30) || n >= (1 << 30)) return false;
   if (f > 256) return false;
@@ -508,6 +517,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.L = w.L; P.T = w.T; P.vec = vec; P.fv = bwd_lanes_per_head(f, vec); P.slot_stride = w.slot_stride;
     P.hpp = DGNN_WAVE / P.fv;
     P.steady = (vec == 4 && h * f / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
+    P.pack_s = bwd_pack_lanes(P.steady != 0, h, P.fv);
     const int hc = bwd_heads_padded(h);
     P.attn_drop = attn_drop; P.slope = negative_slope;
     P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
@@ -783,6 +793,7 @@ int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const
   P.T = (nnz + P.L - 1) / P.L;
   P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
   P.steady = (vec == 4 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
+  P.pack_s = bwd_pack_lanes(P.steady != 0, kernels, P.fv);
   P.slot_stride = (int)align_up((size_t)kernels * embed + kernels, 4);
   P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
   P.in_feat = node_feat; P.grad = grad; P.grad_feat = grad_node_feat; P.grad_attn_col = nullptr;

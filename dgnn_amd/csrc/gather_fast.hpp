@@ -96,7 +96,9 @@ static inline size_t fast_lds_bytes(int H, int L, bool packed = false) {
 // Packed gather (rows of at most 32 float4 slots): lanes per row = the power of two covering the
 // row's slots, at least 4 (so at most 16 edges share one load instruction); 0 = not applicable.
 static inline int fast_pack_lanes(int rowv, bool vec4) {
-  if (!vec4 || rowv > 32) return 0;
+  // two edges per step (rows of 17..32 slots) measured SLOWER than one (2 x 64 forward 5.2 -> 5.6 ms
+  // on the products shape): packing starts at four edges per step.  DGNN_PACK_MAX_S: tuning runs.
+  if (!vec4 || rowv > env_int("DGNN_PACK_MAX_S", 16)) return 0;
   int s = 4;
   while (s < rowv) s <<= 1;
   return s;
