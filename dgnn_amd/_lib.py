@@ -52,6 +52,8 @@ SIGNATURES = {
     "dgnn_gmm_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),
     "dgnn_gmm_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_gmm_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp]),
+    "dgnn_gmm_forward_sum": (_i, [_i, _i, _i, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),
+    "dgnn_gmm_backward_sum": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_vp, _sz, _vp]),
     "dgnn_gaussian": (_i, [_i, _i, _i] + [_vp] * 4 + [_vp]),
     "dgnn_gaussian_backward_workspace_bytes": (_sz, [_i, _i, _i]),
     "dgnn_gaussian_backward": (_i, [_i, _i, _i] + [_vp] * 7 + [_vp, _sz, _vp]),

@@ -53,6 +53,8 @@ struct BwdParams {
   // coordinates (CSR order, fetched through permute); dE receives the raw dots = grad_gauss
   const float *pseudo, *mu, *inv_sigma;
   int dim;
+  int grad_sum;        // BWD_GMM: grad is [m,F], the gradient of the output SUMMED over the kernels
+                       // (every kernel's lanes read the same row slice): gmmconv_layer.py:58 folded in
 };
 
 enum { BWD_GAT = 0, BWD_GMM = 1 };
@@ -315,6 +317,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     const int head = ln.head;
     const size_t lane_off = ln.off;
     const bool head_leader = ln.leader;
+    // grad rows: [m,H,F] like the feature rows, or [m,F] shared by all kernels (BWD_GMM, grad_sum)
+    const bool gsum = (BMODE == BWD_GMM) && P.grad_sum != 0;
+    const size_t gstride = gsum ? (size_t)P.F : (size_t)P.HF;
+    const size_t goff = gsum ? lane_off - (size_t)head * P.F : lane_off;
     vec_t u = V::zero();
     vec_t acc = V::zero();
     float dsum = 0.f;
@@ -335,13 +341,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         const int phead = act ? hd : 0;
         const size_t poff = act ? (size_t)phead * P.F + (size_t)qq * 4 : 0;
         const bool pleader = act && qq == 0;
+        const size_t pgoff = (BMODE == BWD_GMM && P.grad_sum) ? (size_t)(act ? qq : 0) * 4 : poff;
         auto issue = [&](int j, float4 &x) {
           const unsigned it = (unsigned)uniform_i32((int)stream[j]);
           const bool isu = (it & DGNN_BWD_UFLAG) != 0u;
           const int p0 = isu ? 0 : (int)(it & 1023u), n = isu ? 0 : (int)((it >> 10) & 15u) + 1;
           const int pe = p0 + (g < n ? g : 0);
           const unsigned r = isu ? (it & DGNN_BWD_IDMASK) : kof[pe];
-          x = *(const float4 *)((isu ? P.in_feat : P.grad) + (size_t)r * P.HF + poff);
+          x = isu ? *(const float4 *)(P.in_feat + (size_t)r * P.HF + poff)
+                  : *(const float4 *)(P.grad + (size_t)r * gstride + pgoff);
         };
         auto consume = [&](const float4 &x, int j) {
           const unsigned it = (unsigned)uniform_i32((int)stream[j]);
@@ -456,7 +464,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           }
         };
         auto row_of = [&](unsigned v) -> const float * {
-          return ((v & DGNN_BWD_UFLAG) ? P.in_feat : P.grad) + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off;
+          return (v & DGNN_BWD_UFLAG) ? P.in_feat + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off
+                                      : P.grad + (size_t)(v & DGNN_BWD_IDMASK) * gstride + goff;
         };
         // unguarded fill and loop: loads issued unconditionally (idle lanes re-read slot 0 of the
         // row), a slot consumed before it is refilled
@@ -498,8 +507,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       ring[i] = V::zero();
       if (i < items) {
         const unsigned v = (unsigned)uniform_i32((int)stream[i]);
-        const float *base = (v & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
-        if (active) ring[i] = *(const vec_t *)(base + (size_t)(v & DGNN_BWD_IDMASK) * P.HF + lane_off);
+        const bool isu = (v & DGNN_BWD_UFLAG) != 0u;
+        if (active) ring[i] = *(const vec_t *)((isu ? P.in_feat : P.grad) + (size_t)(v & DGNN_BWD_IDMASK) * (isu ? (size_t)P.HF : gstride) +
+                                               (isu ? lane_off : goff));
       }
     }
     for (int j = 0; j < items; j += DGNN_FAST_U) {
@@ -511,8 +521,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           const unsigned v = (unsigned)uniform_i32((int)stream[it]);
           if (it + DGNN_FAST_U < items) {
             const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
-            const float *base = (nv & DGNN_BWD_UFLAG) ? P.in_feat : P.grad;
-            if (active) ring[i] = *(const vec_t *)(base + (size_t)(nv & DGNN_BWD_IDMASK) * P.HF + lane_off);
+            const bool isu = (nv & DGNN_BWD_UFLAG) != 0u;
+            if (active) ring[i] = *(const vec_t *)((isu ? P.in_feat : P.grad) + (size_t)(nv & DGNN_BWD_IDMASK) * (isu ? (size_t)P.HF : gstride) +
+                                                   (isu ? lane_off : goff));
           }
           if (v & DGNN_BWD_UFLAG) {
             u = x;

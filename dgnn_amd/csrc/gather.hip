@@ -767,11 +767,11 @@ size_t dgnn_gmm_backward_workspace_bytes(int nodes, int nnz, int kernels, int em
   return align_up(sizeof(int) * (T > 0 ? T : 1), 256) + align_up(sizeof(float) * 2 * T * stride, 256);
 }
 
-int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
-                      const int *row_ind, const int *permute, const float *node_feat,
-                      const float *pseudo, const float *mu, const float *inv_sigma,
-                      const float *grad, float *grad_node_feat, float *grad_gauss,
-                      void *workspace, size_t workspace_bytes, void *stream) {
+static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
+                             const int *row_ind, const int *permute, const float *node_feat,
+                             const float *pseudo, const float *mu, const float *inv_sigma,
+                             const float *grad, int grad_sum, float *grad_node_feat, float *grad_gauss,
+                             void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(nodes, nnz, kernels, embed);
   if (rc) return rc;
   if (dim <= 0) return DGNN_ERR_BAD_ARG;
@@ -799,6 +799,7 @@ int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const
   P.in_feat = node_feat; P.grad = grad; P.grad_feat = grad_node_feat; P.grad_attn_col = nullptr;
   P.dE = grad_gauss;
   P.pseudo = pseudo; P.mu = mu; P.inv_sigma = inv_sigma; P.dim = dim;
+  P.grad_sum = grad_sum ? 1 : 0;
   P.task_col0 = (int *)workspace;
   P.slots = (float *)((char *)workspace + align_up(sizeof(int) * (size_t)(P.T > 0 ? P.T : 1), 256));
   {
@@ -822,26 +823,51 @@ int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const
   return DGNN_OK;
 }
 
+int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
+                      const int *row_ind, const int *permute, const float *node_feat,
+                      const float *pseudo, const float *mu, const float *inv_sigma,
+                      const float *grad, float *grad_node_feat, float *grad_gauss,
+                      void *workspace, size_t workspace_bytes, void *stream) {
+  return gmm_backward_impl(nodes, nnz, kernels, dim, embed, col_ptr, row_ind, permute, node_feat, pseudo, mu,
+                           inv_sigma, grad, 0, grad_node_feat, grad_gauss, workspace, workspace_bytes, stream);
+}
+
+int dgnn_gmm_backward_sum(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
+                          const int *row_ind, const int *permute, const float *node_feat,
+                          const float *pseudo, const float *mu, const float *inv_sigma,
+                          const float *grad_sum, float *grad_node_feat, float *grad_gauss,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+  return gmm_backward_impl(nodes, nnz, kernels, dim, embed, col_ptr, row_ind, permute, node_feat, pseudo, mu,
+                           inv_sigma, grad_sum, 1, grad_node_feat, grad_gauss, workspace, workspace_bytes, stream);
+}
+
 size_t dgnn_gmm_forward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
   if (nodes < 0 || nnz < 0 || kernels <= 0 || embed <= 0) return 0;
   return fwd_layout(nnz, kernels, embed).total;
 }
 
-int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
-                     const int *col_ind, const float *node_feat, const float *pseudo,
-                     const float *mu, const float *inv_sigma, float *out, void *workspace,
-                     size_t workspace_bytes, void *stream) {
+// float4 rows of at most 64 slots, one lane pass: where the sum over kernels can be folded into the store
+static bool gmm_sum_shape(int nodes, int kernels, int embed) {
+  return fwd_fast_ok(nodes, kernels) && embed % 4 == 0 && kernels * embed / 4 <= DGNN_WAVE;
+}
+
+static int gmm_forward_impl(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
+                            const int *col_ind, const float *node_feat, const float *pseudo,
+                            const float *mu, const float *inv_sigma, float *out, int sum_kernels,
+                            void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(nodes, nnz, kernels, embed);
   if (rc) return rc;
   if (dim <= 0) return DGNN_ERR_BAD_ARG;
   if (nodes == 0) return DGNN_OK;
   if (!csr_ptr || !mu || !inv_sigma || !out || (nnz > 0 && (!col_ind || !pseudo || !node_feat)))
     return DGNN_ERR_BAD_ARG;
+  if (sum_kernels && !(gmm_sum_shape(nodes, kernels, embed) && aligned16(node_feat) && aligned16(out)))
+    return DGNN_ERR_UNSUPPORTED;
   if (fwd_fast_ok(nodes, kernels)) {
     GatherParams P = {};
     P.m = nodes; P.nnz = nnz; P.H = kernels; P.F = embed; P.dim = dim;
     P.row_ptr = csr_ptr; P.col_ind = col_ind; P.pseudo = pseudo; P.mu = mu; P.inv_sigma = inv_sigma;
-    P.in_feat = node_feat; P.out = out;
+    P.in_feat = node_feat; P.out = out; P.sum_heads = sum_kernels ? 1 : 0;
     return launch_fast_gather<MODE_GMM>(P, workspace, workspace_bytes, (hipStream_t)stream);
   }
   hipLaunchKernelGGL(k_spmm_row<1>, dim3(blocks_for_waves(nodes)), dim3(DGNN_BLOCK), 0,
@@ -849,6 +875,22 @@ int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const 
                      (const float *)nullptr, pseudo, mu, inv_sigma, node_feat, out);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
+}
+
+int dgnn_gmm_forward(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
+                     const int *col_ind, const float *node_feat, const float *pseudo,
+                     const float *mu, const float *inv_sigma, float *out, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  return gmm_forward_impl(nodes, nnz, kernels, dim, embed, csr_ptr, col_ind, node_feat, pseudo, mu, inv_sigma, out,
+                          0, workspace, workspace_bytes, stream);
+}
+
+int dgnn_gmm_forward_sum(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
+                         const int *col_ind, const float *node_feat, const float *pseudo,
+                         const float *mu, const float *inv_sigma, float *out_sum, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  return gmm_forward_impl(nodes, nnz, kernels, dim, embed, csr_ptr, col_ind, node_feat, pseudo, mu, inv_sigma,
+                          out_sum, 1, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

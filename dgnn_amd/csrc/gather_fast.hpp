@@ -43,6 +43,8 @@ struct GatherParams {
   int rowv;                          // HF / VEC : vector slots per feature row
   int slot_stride;                   // floats per partial slot (HF + 2H rounded up to 4)
   int dim;                           // GMM pseudo dimension
+  int sum_heads;                     // != 0: out is [m,F] = the sum over the H heads / kernels (GMMConv layer:
+                                     // gmmconv_layer.py:58 `.sum(1)`), folded into the store; rows of <= 64 float4 slots
   int steady;                        // narrow rows: unguarded steady-state gather loop (phase C)
   int pack_s;                        // > 0: lanes per row of the PACKED gather (rows of <= 32 float4 slots:
                                      // 64 / pack_s edges of a row per load instruction), see phase C
@@ -78,8 +80,10 @@ static inline bool narrow_rows(int H, int F) { return F % 4 == 0 && H * F / 4 < 
 // Tuning override (multiples of 16): DGNN_FWD_L.
 static inline int fast_group_size(int H, int nnz, bool narrow = false) {
   int dflt = H <= 4 ? 512 : 256;
-  if (narrow)
-    while (dflt > 64 && (size_t)dflt * (H + 2) * sizeof(float) > 6144) dflt >>= 1;
+  // narrow rows, re-swept with the packed gather (tools/sweep_narrow.sh, round 2): one head 256
+  // (products shape 1 x 16: 2.5 -> 2.0 ms, 1 x 48: 3.1 -> 2.8; Reddit shape +2 %), more heads 128
+  // (2 x 32: 3.9 -> 3.6, 4 x 16: 4.1 -> 3.8)
+  if (narrow) dflt = H == 1 ? 256 : 128;
   const int v = env_int("DGNN_FWD_L", 0);
   if (v >= 16 && v <= 1024 && v % 16 == 0) return v;
   // down to 16 edges per wave: a Cora-sized forward 39 -> 19 us (a group is a chain of dependent
@@ -112,8 +116,9 @@ __global__ void k_fast_prep_rows(GatherParams P) {
        r += (long long)gridDim.x * blockDim.x) {
     const int lb = P.row_ptr[r], hb = P.row_ptr[r + 1];
     if (lb == hb) {
-      float *o = P.out + (size_t)r * P.HF;
-      for (int i = 0; i < P.HF; ++i) o[i] = 0.f;
+      const int width = P.sum_heads ? P.F : P.HF;
+      float *o = P.out + (size_t)r * width;
+      for (int i = 0; i < width; ++i) o[i] = 0.f;
       if (P.edge_max != nullptr)
         for (int h = 0; h < P.H; ++h) {
           P.edge_max[(size_t)r * P.H + h] = DGNN_NEG_INIT;
@@ -181,6 +186,24 @@ __device__ __forceinline__ void st_heads(float *p, const float (&d)[HT]) {
 #pragma unroll
     for (int i = 0; i < HT; ++i) p[i] = d[i];
   }
+}
+
+// Store of a finished WHOLE row when the output is the sum over heads (P.sum_heads; float4 lanes, one
+// slot per lane): the lane of head 0 that owns feature slot fs adds the accumulators of the lanes
+// that own the same slot of heads 1 .. H-1 (they sit F/4 lanes apart) and writes out[row, fs].
+__device__ __forceinline__ void store_row_summed(const GatherParams &P, int row, bool active, int head, size_t lane_off,
+                                                 float4 acc) {
+  const int lane = lane_id();
+  const int per_head = P.F / 4;
+  float4 tot = acc;
+  for (int h = 1; h < P.H; ++h) {
+    const int src = lane + h * per_head;
+    tot.x += __shfl(acc.x, src, DGNN_WAVE);
+    tot.y += __shfl(acc.y, src, DGNN_WAVE);
+    tot.z += __shfl(acc.z, src, DGNN_WAVE);
+    tot.w += __shfl(acc.w, src, DGNN_WAVE);
+  }
+  if (active && head == 0) *(float4 *)(P.out + (size_t)row * P.F + lane_off) = tot;
 }
 
 // HT = compile-time head count of the all-heads-at-once softmax phase for 1, 2 or 8 heads
@@ -475,8 +498,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           }
           const int d = uniform_i32(dq[q]);
           ++q;
-          float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
-          if (active && g == 0) *(float4 *)(dst + lane_off) = acc;
+          if (MODE != MODE_GAT && P.sum_heads && d >= 0) {
+            store_row_summed(P, d, active && g == 0, head, lane_off, acc);
+          } else {
+            float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+            if (active && g == 0) *(float4 *)(dst + lane_off) = acc;
+          }
           acc = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       };
@@ -533,6 +560,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     vec_t acc[NS];
     vec_t ring[DGNN_FAST_U][NS];
     float wring[DGNN_FAST_U][NS];
+    int hd0 = 0;                           // head of the lane's first slot (summed store)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int vslot = fb * span + s * DGNN_WAVE + lane;
@@ -541,6 +569,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       lane_off[s] = (size_t)(active[s] ? vslot : 0) * VEC;
       wbase[s] = sc + head;
       acc[s] = V::zero();
+      if (s == 0) hd0 = head;
     }
     int q = 0;
     bool took_steady = false;
@@ -552,6 +581,13 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       if (ci & DGNN_ROWEND) {
         const int d = uniform_i32(dq[q]);
         ++q;
+        if constexpr (MODE != MODE_GAT && NS == 1 && VEC == 4) {
+          if (P.sum_heads && d >= 0) {
+            store_row_summed(P, d, active[0], hd0, lane_off[0], acc[0]);
+            acc[0] = V::zero();
+            return;
+          }
+        }
         float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -674,12 +710,22 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             if (ci & DGNN_ROWEND) {
               const int d = uniform_i32(dq[q]);
               ++q;
-              float *dst = (d >= 0) ? P.out + (size_t)d * P.HF
-                                    : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
+              bool stored = false;
+              if constexpr (MODE != MODE_GAT && NS == 1 && VEC == 4) {
+                if (P.sum_heads && d >= 0) {
+                  store_row_summed(P, d, active[0], hd0, lane_off[0], acc[0]);
+                  acc[0] = V::zero();
+                  stored = true;
+                }
+              }
+              if (!stored) {
+                float *dst = (d >= 0) ? P.out + (size_t)d * P.HF
+                                      : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
 #pragma unroll
-              for (int s = 0; s < NS; ++s) {
-                if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
-                acc[s] = V::zero();
+                for (int s = 0; s < NS; ++s) {
+                  if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
+                  acc[s] = V::zero();
+                }
               }
             }
           }
@@ -777,7 +823,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
         for (int j = 0; j < FB; ++j)
           if (i0 + j < npieces) { acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w; }
       }
-      if (active) {
+      if (P.sum_heads) {     // host guarantees float4 lanes and a single lane pass here
+        store_row_summed(P, r, active, head, (size_t)(fid - head * P.F), make_float4(acc[0], acc[1], acc[2], acc[3]));
+      } else if (active) {
         if (vec4)
           *(float4 *)(P.out + (size_t)r * P.HF + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else

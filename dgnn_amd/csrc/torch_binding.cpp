@@ -591,6 +591,54 @@ py::object gmm_backward_fused(const Tensor &colptr, const Tensor &rowind, const 
   return py::cast(std::make_tuple(grad_feat, grad_gauss));
 }
 
+// ---- GMMConv with the layer's sum over the kernels folded in (include/dgnn_hip.h: dgnn_gmm_*_sum)
+// -> out_sum [nodes, embed] = gmmconv(...).sum(1), or None where the summed kernels do not apply
+py::object gmmconv_sum(const Tensor &csrptr, const Tensor &colind, const Tensor &node_feat, const Tensor &pseudo,
+                       const Tensor &mu, const Tensor &inv_sigma) {
+  i32(csrptr, "csrptr"), i32(colind, "colind"), f32(node_feat, "node_feat", 3), f32(pseudo, "pseudo", 2);
+  f32(mu, "mu", 2), f32(inv_sigma, "inv_sigma", 2);
+  const int nodes = as_int(csrptr.size(0) - 1, "nodes"), nnz = as_int(colind.size(0), "nnz");
+  const int k = as_int(mu.size(0), "kernels"), dim = as_int(mu.size(1), "dim");
+  const int embed = as_int(node_feat.size(2), "features");
+  if (node_feat.size(1) != k || pseudo.size(0) != nnz || pseudo.size(1) != dim)
+    fail("gmmconv_sum: node_feat [n,K,F], pseudo [nnz,dim], mu [K,dim] disagree");
+  c10::DeviceGuard guard(node_feat.device());
+  Tensor out = new_f32({nodes, embed}, node_feat);
+  const size_t nb = API(dgnn_gmm_forward_workspace_bytes)(nodes, nnz, k, embed);
+  Tensor ws = workspace(nb, node_feat);
+  const int rc = API(dgnn_gmm_forward_sum)(nodes, nnz, k, dim, embed, ip(csrptr), ip(colind), fp(node_feat), fp(pseudo),
+                                           fp(mu), fp(inv_sigma), fo(out), ptr<void>(ws), nb, stream_of(node_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gmm_forward_sum");
+  return py::cast(out);
+}
+
+// -> (grad_node_feat [nodes,K,embed], grad_gauss [E,K]) from grad_sum [nodes, embed], or None
+py::object gmm_backward_fused_sum(const Tensor &colptr, const Tensor &rowind, const Tensor &permute,
+                                  const Tensor &node_feat, const Tensor &pseudo, const Tensor &mu,
+                                  const Tensor &inv_sigma, const Tensor &grad_sum) {
+  i32(colptr, "colptr"), i32(rowind, "rowind"), i32(permute, "permute");
+  f32(node_feat, "node_feat", 3), f32(pseudo, "pseudo", 2), f32(grad_sum, "grad_sum", 2);
+  f32(mu, "mu", 2), f32(inv_sigma, "inv_sigma", 2);
+  const int nodes = as_int(colptr.size(0) - 1, "nodes"), nnz = as_int(rowind.size(0), "nnz");
+  const int kernels = as_int(node_feat.size(1), "kernels"), embed = as_int(node_feat.size(2), "features");
+  const int dim = as_int(pseudo.size(1), "dim");
+  if (grad_sum.size(0) != nodes || grad_sum.size(1) != embed || pseudo.size(0) != nnz || node_feat.size(0) != nodes)
+    fail("gmm_backward_fused_sum: grad_sum [n,F] / node_feat [n,K,F] / pseudo shapes disagree with the graph");
+  const size_t nb = API(dgnn_gmm_backward_workspace_bytes)(nodes, nnz, kernels, embed);
+  if (nb == 0) return py::none();
+  c10::DeviceGuard guard(node_feat.device());
+  Tensor grad_feat = at::empty_like(node_feat);
+  Tensor grad_gauss = new_f32({nnz, kernels}, node_feat);
+  Tensor ws = workspace(nb, node_feat);
+  const int rc = API(dgnn_gmm_backward_sum)(nodes, nnz, kernels, dim, embed, ip(colptr), ip(rowind), ip(permute),
+                                            fp(node_feat), fp(pseudo), fp(mu), fp(inv_sigma), fp(grad_sum),
+                                            fo(grad_feat), fo(grad_gauss), ptr<void>(ws), nb, stream_of(node_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gmm_backward_sum");
+  return py::cast(std::make_tuple(grad_feat, grad_gauss));
+}
+
 // ================================================================== fused_edgeconv / knn
 // -> [out_feat, max_idx]; max_idx is a float32 tensor holding ids, as in the reference
 // (fused_edgeconv_kernel.cu:46,61).  return_int_idx additionally returns the exact int32 copy
@@ -908,6 +956,13 @@ PYBIND11_MODULE(fused_gmmconv, m) {
   def(m, "GaussianBp", &GaussianBp, "pseudo, mu, inv_sigma, grad_out",
       "-> [pseudo_out, mu_out, sigma_out]   (fused_gmmconv.cpp:49-57); analytic gradient", arg("pseudo"), arg("mu"),
       arg("inv_sigma"), arg("grad_out"));
+  def(m, "gmmconv_sum", &gmmconv_sum, "csrptr, colind, node_feat, pseudo, mu, inv_sigma",
+      "-> out_sum [nodes, embed] = gmmconv(...).sum(1) with the sum folded into the store (gmmconv_layer.py:58), or None",
+      arg("csrptr"), arg("colind"), arg("node_feat"), arg("pseudo"), arg("mu"), arg("inv_sigma"));
+  def(m, "gmm_backward_fused_sum", &gmm_backward_fused_sum,
+      "colptr, rowind, permute, node_feat, pseudo, mu, inv_sigma, grad_sum",
+      "gmm_backward_fused for grad_sum [nodes, embed], the gradient of the summed output; or None", arg("colptr"),
+      arg("rowind"), arg("permute"), arg("node_feat"), arg("pseudo"), arg("mu"), arg("inv_sigma"), arg("grad_sum"));
   def(m, "gmm_backward_fused", &gmm_backward_fused,
       "colptr, rowind, permute, node_feat, pseudo, mu, inv_sigma, grad_out",
       "-> (grad_node_feat, grad_gauss [E,K] in CSR order) or None (shape outside the one-pass kernel)", arg("colptr"),

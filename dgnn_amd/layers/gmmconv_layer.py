@@ -3,7 +3,7 @@ import torch as th
 from torch import nn
 from torch.nn import init
 
-from ..operators.fused_gmmconv import GmmConvFuse
+from ..operators.fused_gmmconv import GmmConvFuseSum
 
 
 class GMMConv(nn.Module):
@@ -46,8 +46,10 @@ class GMMConv(nn.Module):
 
     def forward(self, rowptr, colind, colptr, rowind, permute, feat, pseudo):
         node_feat = self.fc(feat).view(-1, self._n_kernels, self._out_feats)
-        rst = GmmConvFuse(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, self.mu,
-                          self.inv_sigma).sum(1)
+        # gmmconv_layer.py:57-58 is GmmConvFuse(...).sum(1): the sum over the kernels is folded
+        # into the operator's store (and the gradient's expand into its backward)
+        rst = GmmConvFuseSum(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, self.mu,
+                             self.inv_sigma)
         if self.res_fc is not None:
             rst = rst + self.res_fc(feat)
         if self.bias is not None:

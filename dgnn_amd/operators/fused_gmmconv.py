@@ -44,3 +44,46 @@ class GmmFuseFunction(torch.autograd.Function):
             node_feat_grad = gmm.gmmconv(colptr, rowind, grad_out, pseudo_tran, mu, sigma)
         pseudo_out, mu_out, sigma_out = gmm.GaussianBp(pseudo, mu, sigma, gaussian_grad)
         return None, None, None, None, None, unpad(node_feat_grad, ctx.f), pseudo_out, mu_out, sigma_out
+
+
+def GmmConvFuseSum(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
+    """``GmmConvFuse(...).sum(1)`` -- what dgNN/layers/gmmconv_layer.py:58 computes -- as ONE
+    operator: the forward stores the [N,F] sum directly (no [N,K,F] write, read-back and reduce),
+    the one-pass backward reads the [N,F] gradient for every kernel (no expand).  Same arithmetic
+    per (row, kernel); shapes the summed kernels do not take fall back to the two-step form."""
+    return GmmFuseSumFunction.apply(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma)
+
+
+class GmmFuseSumFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
+        ctx.f = node_feat.size(2)
+        node_feat, pseudo = pad4(node_feat.contiguous()), pseudo.contiguous()
+        mu, sigma = mu.contiguous(), sigma.contiguous()
+        out = gmm.gmmconv_sum(rowptr, colind, node_feat, pseudo, mu, sigma)
+        if out is None:
+            out = gmm.gmmconv(rowptr, colind, node_feat, pseudo, mu, sigma).sum(1)
+        ctx.save_for_backward(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma)
+        return out if out.size(1) == ctx.f else out[:, :ctx.f]
+
+    @staticmethod
+    def backward(ctx, grad_sum):
+        rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma = ctx.saved_tensors
+        fp = node_feat.size(2)
+        if grad_sum.size(1) != fp:
+            grad_sum = torch.nn.functional.pad(grad_sum, (0, fp - grad_sum.size(1)))
+        grad_sum = grad_sum.contiguous()
+        fused = gmm.gmm_backward_fused_sum(colptr, rowind, permute, node_feat, pseudo, mu, sigma, grad_sum)
+        if fused is not None:
+            node_feat_grad, gaussian_grad = fused
+        else:
+            grad_out = grad_sum.unsqueeze(1).expand(-1, node_feat.size(1), -1).contiguous()
+            fused = gmm.gmm_backward_fused(colptr, rowind, permute, node_feat, pseudo, mu, sigma, grad_out)
+            if fused is not None:
+                node_feat_grad, gaussian_grad = fused
+            else:
+                gaussian_grad = mhsddmm.mhsddmm(rowptr, colind, grad_out, node_feat)
+                pseudo_tran = mhtranspose.mhtranspose(permute, pseudo)
+                node_feat_grad = gmm.gmmconv(colptr, rowind, grad_out, pseudo_tran, mu, sigma)
+        pseudo_out, mu_out, sigma_out = gmm.GaussianBp(pseudo, mu, sigma, gaussian_grad)
+        return None, None, None, None, None, unpad(node_feat_grad, ctx.f), pseudo_out, mu_out, sigma_out

@@ -336,6 +336,26 @@ int dgnn_gmm_backward(int nodes, int nnz, int kernels, int dim, int embed, const
                       const float *grad, float *grad_node_feat, float *grad_gauss,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* The GMMConv LAYER sums the operator's output over the kernels right away
+ * (dgNN/layers/gmmconv_layer.py:58: `GmmConvFuse(...).sum(1)`), i.e. it writes [nodes,K,F], reads it
+ * back and writes [nodes,F], and autograd expands the [nodes,F] gradient to [nodes,K,F] again.
+ * These two fold that sum into the kernels: the forward stores out_sum [nodes,F] = sum_k out[:,k,:]
+ * directly (the K partial rows of a node sit in one wave and are added across lanes before the
+ * store), and the one-pass backward reads grad_sum [nodes,F] for every kernel's lanes.  Same
+ * arithmetic per (row, kernel) as dgnn_gmm_forward / dgnn_gmm_backward; the sum over kernels is
+ * taken in ascending k.  Shapes: embed % 4 == 0, kernels * embed / 4 <= 64, 16-byte aligned rows
+ * (and the conditions of dgnn_gmm_backward for the backward); otherwise DGNN_ERR_UNSUPPORTED and
+ * the caller keeps the unsummed entry points.  Workspaces: the queries of the unsummed twins. */
+int dgnn_gmm_forward_sum(int nodes, int nnz, int kernels, int dim, int embed, const int *csr_ptr,
+                         const int *col_ind, const float *node_feat, const float *pseudo,
+                         const float *mu, const float *inv_sigma, float *out_sum,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int dgnn_gmm_backward_sum(int nodes, int nnz, int kernels, int dim, int embed, const int *col_ptr,
+                          const int *row_ind, const int *permute, const float *node_feat,
+                          const float *pseudo, const float *mu, const float *inv_sigma,
+                          const float *grad_sum, float *grad_node_feat, float *grad_gauss,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* Exact k-nearest-neighbour graph per point cloud: x [batch, points, dim] -> src_ind
  * [batch*points*k], src_ind[r*k + t] = global id (cloud offset included) of the t-th nearest
  * point of r within r's cloud, r itself included, ascending distance, ties -> lower id: the

@@ -471,6 +471,59 @@ def test_gmm_autograd_operator(nat, f, pad_rows):
     assert_close(host(sg.grad), SG.grad.numpy(), "GmmConvFuse: grad inv_sigma", mass=m_sg)
 
 
+@pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("k,f", [(3, 64), (2, 16), (3, 16), (1, 8), (5, 8), (3, 41), (2, 100), (8, 64)])
+@pytest.mark.parametrize("fwd_l", [0, 64])
+def test_gmm_sum_over_kernels_folded_into_the_operator(nat, name, k, f, fwd_l, monkeypatch):
+    """GmmConvFuseSum == GmmConvFuse(...).sum(1) (dgNN/layers/gmmconv_layer.py:58) with the sum in
+    the kernels' store and the gradient's expand in the one-pass backward: forward and every
+    gradient against float64 torch autograd; rows cut by group boundaries (small groups forced on
+    the hub graph) take the partial-slot path; 8 x 64 is outside the summed kernels (fallback)."""
+    from dgnn_amd.operators import GmmConvFuseSum
+    if fwd_l:
+        monkeypatch.setenv("DGNN_FWD_L", str(fwd_l))
+        monkeypatch.setenv("DGNN_BWD_L", "64")
+    g = GRAPHS[name]
+    G = gdev(g)
+    d = 2
+    rng = np.random.default_rng(k * 10 + f)
+    node_feat = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    pseudo = rng.random((g["nnz"], d), dtype=np.float32)
+    mu = (0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    inv_sigma = (1 + 0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    go = rng.standard_normal((g["n"], f)).astype(np.float32)
+    x, ps, m_, sg = (dev(t).requires_grad_() for t in (node_feat, pseudo, mu, inv_sigma))
+    out = GmmConvFuseSum(G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], x, ps, m_, sg)
+    assert out.shape == (g["n"], f)
+    out.backward(dev(go))
+    row = torch.from_numpy(np.repeat(np.arange(g["n"]), np.diff(g["row_ptr"]))).long()
+    col = torch.from_numpy(g["col_ind"]).long()
+    X = torch.tensor(node_feat, dtype=torch.float64, requires_grad=True)
+    PS = torch.tensor(pseudo, dtype=torch.float64, requires_grad=True)
+    M = torch.tensor(mu, dtype=torch.float64, requires_grad=True)
+    SG = torch.tensor(inv_sigma, dtype=torch.float64, requires_grad=True)
+    gauss = torch.exp(-0.5 * (((PS[:, None, :] - M[None]) * SG[None]) ** 2).sum(-1))
+    ref = torch.zeros_like(X).index_add(0, row, gauss[:, :, None] * X[col]).sum(1)
+    ref.backward(torch.tensor(go, dtype=torch.float64))
+    go_k = np.repeat(go[:, None, :], k, 1)
+    m_out = oracle.gmmconv_f64(g["row_ptr"], g["col_ind"], np.abs(node_feat), pseudo, mu, inv_sigma).sum(1)
+    m_gx = oracle.gmmconv_f64(g["col_ptr"], g["row_ind"], np.abs(go_k), pseudo[g["permute"]], mu, inv_sigma)
+    m_gg = oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], np.abs(go_k), np.abs(node_feat))
+    m_ps, m_mu, m_sg = gaussian_bp_masses(pseudo, mu, inv_sigma, m_gg)
+    assert_close(host(out), ref.detach().numpy(), "GmmConvFuseSum: out", mass=m_out)
+    assert_close(host(x.grad), X.grad.numpy(), "GmmConvFuseSum: grad node_feat", mass=m_gx)
+    assert_close(host(ps.grad), PS.grad.numpy(), "GmmConvFuseSum: grad pseudo", mass=m_ps)
+    assert_close(host(m_.grad), M.grad.numpy(), "GmmConvFuseSum: grad mu", mass=m_mu)
+    assert_close(host(sg.grad), SG.grad.numpy(), "GmmConvFuseSum: grad inv_sigma", mass=m_sg)
+    if (k, f) == (3, 64):
+        # the summed kernels really ran (not the fallback) and agree with the two-step form
+        assert nat["gmm"].gmmconv_sum(G["row_ptr"], G["col_ind"], dev(node_feat), dev(pseudo), dev(mu), dev(inv_sigma)) is not None
+        two = nat["gmm"].gmmconv(G["row_ptr"], G["col_ind"], dev(node_feat), dev(pseudo), dev(mu), dev(inv_sigma)).sum(1)
+        assert torch.allclose(out.detach(), two, rtol=1e-5, atol=1e-5)
+    if (k, f) == (8, 64):
+        assert nat["gmm"].gmmconv_sum(G["row_ptr"], G["col_ind"], dev(node_feat), dev(pseudo), dev(mu), dev(inv_sigma)) is None
+
+
 @pytest.mark.parametrize("k", [1, 5, 20, 32, 33, 40, 70])
 @pytest.mark.parametrize("f", [9, 64, 130])
 def test_edgeconv_bit_exact_argmax(nat, k, f):
