@@ -106,6 +106,14 @@ def chunk_fractions(chunks):
     return [0.5 ** (chunks - 1)] + [0.5 ** (chunks - i) for i in range(1, chunks)]
 
 
+class _NoWait:
+    """Stand-in for a collective's work handle where the exchange ran synchronously on the pack
+    stream (one rank, rehearsal copies): the chunk's event carries the ordering."""
+
+    def wait(self):
+        return None
+
+
 class _Halo:
     """Who needs which of my rows, and which rows I need, for ONE chunk of one direction."""
 
@@ -297,9 +305,14 @@ class PartitionedGAT:
 
     @staticmethod
     def _wait(handles):
-        for h in handles:
+        """Order the CURRENT stream after one chunk's exchange: the collectives' own handles (RCCL
+        stream) and the event recorded on the pack stream behind them (local copies / staged paths)."""
+        hs, ev = handles if isinstance(handles, tuple) else (handles, None)
+        for h in hs:
             if h is not None:
                 h[0].wait()
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _pack(self, local, h):
         """The rows of ``local`` the peers want for this chunk, as one contiguous message."""
@@ -311,15 +324,42 @@ class PartitionedGAT:
     def _start_fetch(self, side, tables, locals_):
         """Start every chunk's exchange, in chunk order: for each chunk the rows the peers need of
         each tensor in ``locals_`` are packed and sent, and the rows this rank needs land directly
-        in their place in ``tables`` (no scatter pass).  -> per-chunk handle lists."""
+        in their place in ``tables`` (no scatter pass).  -> per-chunk (handle list, event).
+
+        On the GPU the packs run on a SIDE stream (ordered after the current stream once, so the
+        inputs are complete): only chunk 0's pack and exchange precede chunk 0's kernels; the packs
+        of the later chunks (1.2 ms per step at 8 ranks on the products shape, as much as one gather
+        pass) overlap the compute stream instead of sitting in front of it.  DGNN_DIST_PACK_STREAM=0
+        issues them on the compute stream as before (A/B runs)."""
+        on_gpu = bool(locals_) and locals_[0].is_cuda and os.environ.get("DGNN_DIST_PACK_STREAM", "1") != "0"
+        if not on_gpu:
+            handles = []
+            for s, h in enumerate(side.halos):
+                hs = []
+                for table, local in zip(tables, locals_):
+                    send = self._pack(local, h)
+                    hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
+                                        h.send_counts, async_op=True))
+                handles.append((hs, None))
+            return handles
+        dev = locals_[0].device
+        if getattr(self, "_pack_stream", None) is None:
+            self._pack_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self._pack_stream.wait_stream(cur)            # inputs (and last step's readers of the tables) are done
         handles = []
-        for s, h in enumerate(side.halos):
-            hs = []
-            for table, local in zip(tables, locals_):
-                send = self._pack(local, h)
-                hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
-                                    h.send_counts, async_op=True))
-            handles.append(hs)
+        with torch.cuda.stream(self._pack_stream):
+            for s, h in enumerate(side.halos):
+                hs = []
+                for table, local in zip(tables, locals_):
+                    send = self._pack(local, h)
+                    hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
+                                        h.send_counts, async_op=True))
+                    if hs[-1] is None:
+                        hs[-1] = (_NoWait(), send)     # keep the message alive until the chunk is consumed
+                ev = torch.cuda.Event()
+                ev.record(self._pack_stream)
+                handles.append((hs, ev))
         return handles
 
     def _return_rows(self, side, partial):

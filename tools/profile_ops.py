@@ -22,8 +22,9 @@ dev = torch.device("cuda:0")
 REPS = int(os.environ.get("DGNN_PROFILE_REPS", "3"))
 
 
-def gmm(workload):
-    from dgnn_amd.operators import GmmConvFuse
+def gmm(workload, summed=False):
+    """summed: the layer's form, out.sum(1): two-step (operator, torch sum; DGNN_GMM_TWO_STEP=1) or folded."""
+    from dgnn_amd.operators import GmmConvFuse, GmmConvFuseSum
     if workload == "pubmed":
         from util import random_graph
         g = random_graph(19717, 88648, 0)
@@ -37,9 +38,23 @@ def gmm(workload):
     mu = (0.1 * torch.randn((K, D), device=dev, generator=gen)).requires_grad_()
     sg = torch.ones((K, D), device=dev).requires_grad_()
     go = torch.randn((g["n"], K, F), device=dev, generator=gen)
-    for _ in range(REPS):
+    gs = torch.randn((g["n"], F), device=dev, generator=gen)
+    G5 = [g[k] for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for i in range(REPS + 1):
+        if i == 1:
+            ev[0].record()
         x.grad = ps.grad = mu.grad = sg.grad = None
-        GmmConvFuse(g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], x, ps, mu, sg).backward(go)
+        if not summed:
+            GmmConvFuse(*G5, x, ps, mu, sg).backward(go)
+        elif os.environ.get("DGNN_GMM_TWO_STEP") == "1":
+            GmmConvFuse(*G5, x, ps, mu, sg).sum(1).backward(gs)
+        else:
+            GmmConvFuseSum(*G5, x, ps, mu, sg).backward(gs)
+    ev[1].record()
+    torch.cuda.synchronize()
+    print(f"gmm {workload} summed={summed} two_step={os.environ.get('DGNN_GMM_TWO_STEP') == '1'}: "
+          f"{ev[0].elapsed_time(ev[1]) / REPS:.3f} ms per fwd+bwd", flush=True)
 
 
 def edgeconv():
@@ -106,7 +121,9 @@ def layer(workload):
 
 if __name__ == "__main__":
     w = sys.argv[1]
-    if w.startswith("gmm_"):
+    if w.startswith("gmmsum_"):
+        gmm(w[7:], summed=True)
+    elif w.startswith("gmm_"):
         gmm(w[4:])
     elif w == "edgeconv":
         edgeconv()
