@@ -265,6 +265,70 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum4_long(const int *__r
   if (threadIdx.x == 0) grad_attn_row[rr] = red[0];
 }
 
+// H == 8: a row's [deg][8] slab is 2*deg float4s; the 16 lanes of a group stride over it, so a lane
+// always holds the same half of the heads (q % 2) and adds whole float4s (the scalar kernel below
+// moves one float per lane: 8 x 8 on the products shape 1.5 + 1.1 ms for the two row-sum kernels).
+// Hub rows are queued for k_gat_row_sum8_long as in the H == 4 pair.  Fixed-order sums.
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum8(int m, const int *__restrict__ row_ptr,
+                                                             const float4 *__restrict__ d4,
+                                                             float4 *__restrict__ grad_attn_row,
+                                                             int *__restrict__ long_count,
+                                                             int *__restrict__ long_list, int long_thr) {
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
+  const int r = blockIdx.x * 16 + grp;
+  if (r >= m) return;
+  const int lb = row_ptr[r], hb = row_ptr[r + 1];
+  if (hb - lb > long_thr) {
+    if (q == 0) long_list[atomicAdd(long_count, 1)] = r;
+    return;
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s = z;
+  const long long beg = 2ll * lb, end = 2ll * hb;
+  for (long long i = beg + q; i < end; i += 32) {
+    const float4 a = d4[i];
+    const float4 c = (i + 16 < end) ? d4[i + 16] : z;
+    s.x += a.x + c.x; s.y += a.y + c.y; s.z += a.z + c.z; s.w += a.w + c.w;
+  }
+#pragma unroll
+  for (int st = 2; st < 16; st <<= 1) {
+    s.x += __shfl_xor(s.x, st, 16); s.y += __shfl_xor(s.y, st, 16);
+    s.z += __shfl_xor(s.z, st, 16); s.w += __shfl_xor(s.w, st, 16);
+  }
+  if (q < 2) grad_attn_row[2ll * r + q] = s;
+}
+
+__global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum8_long(const int *__restrict__ row_ptr,
+                                                                  const float4 *__restrict__ d4,
+                                                                  float4 *__restrict__ grad_attn_row,
+                                                                  const int *__restrict__ long_count,
+                                                                  const int *__restrict__ long_list) {
+  __shared__ float4 red[DGNN_BLOCK];
+  if ((int)blockIdx.x >= *long_count) return;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int rr = long_list[blockIdx.x];
+  const long long beg = 2ll * row_ptr[rr], end = 2ll * row_ptr[rr + 1];
+  float4 s0 = z, s1 = z;
+  for (long long i = beg + (int)threadIdx.x; i < end; i += 2 * DGNN_BLOCK) {
+    const float4 a0 = d4[i];
+    const float4 a1 = (i + DGNN_BLOCK < end) ? d4[i + DGNN_BLOCK] : z;
+    s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+    s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+  }
+  red[threadIdx.x] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  __syncthreads();
+  for (int st = DGNN_BLOCK / 2; st >= 2; st >>= 1) {        // down to stride 2: the two head halves stay apart
+    if ((int)threadIdx.x < st) {
+      const float4 o = red[threadIdx.x + st];
+      float4 mine = red[threadIdx.x];
+      mine.x += o.x; mine.y += o.y; mine.z += o.z; mine.w += o.w;
+      red[threadIdx.x] = mine;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) grad_attn_row[2ll * rr + threadIdx.x] = red[threadIdx.x];
+}
+
 // Any H: one 16-lane group per row; rows above `long_thr` edges are queued for
 // k_gat_row_sum_long (one block per row), as in the H == 4 pair above.
 __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum(int m, int H,

@@ -584,6 +584,14 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
       hipLaunchKernelGGL(k_gat_row_sum4_long, dim3(w.max_long), dim3(DGNN_BLOCK), 0, st, row_ptr,
                          (const float4 *)dE, (float4 *)grad_attn_row, (const int *)long_count,
                          (const int *)(long_count + 1));
+    } else if (h == 8 && aligned16(dE) && aligned16(grad_attn_row)) {
+      hipLaunchKernelGGL(k_gat_row_sum8, dim3((m + 15) / 16), dim3(DGNN_BLOCK), 0, st, m, row_ptr,
+                         (const float4 *)dE, (float4 *)grad_attn_row, long_count, long_count + 1,
+                         rowsum_long_threshold());
+      DGNN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_gat_row_sum8_long, dim3(w.max_long), dim3(DGNN_BLOCK), 0, st, row_ptr,
+                         (const float4 *)dE, (float4 *)grad_attn_row, (const int *)long_count,
+                         (const int *)(long_count + 1));
     } else {
       hipLaunchKernelGGL(k_gat_row_sum, dim3((m + 15) / 16), dim3(DGNN_BLOCK), 0, st, m, h, row_ptr,
                          dE, grad_attn_row, long_count, long_count + 1, rowsum_long_threshold());
