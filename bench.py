@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--simulate-rank", default=None, metavar="R/N",
                     help="time rank R of an N-rank partition ALONE on this GPU, exchanges replaced by local "
                          "copies of the same size (everything but the wire; results are not meaningful)")
+    ap.add_argument("--no-other-labels", action="store_true",
+                    help="skip the extra steps on the other node labelling (profiling runs: one labelling per trace)")
     ap.add_argument("--dry", action="store_true", help="launcher check: gloo all-reduce on the CPU, no GPU work")
     args = ap.parse_args()
 
@@ -438,7 +440,8 @@ def main():
             line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
                                  f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")
             line["value"] = runner.nnz_fwd / (ms_per_step * 1e-3)
-        if world == 1 and not use_pg and not args.force_dist and not args.simulate_rank and args.workload != "cora":
+        if (world == 1 and not use_pg and not args.force_dist and not args.simulate_rank and args.workload != "cora"
+                and not args.no_other_labels):
             # the same step on the other labelling of the same graph (continuity with round 1,
             # which ran on the generator's ids)
             other = "natural" if args.labels == "scrambled" else "scrambled"

@@ -9,8 +9,8 @@ set -u
 tag=${1:-r2}; name=${2:-products}; shift 2 || true
 root=${GRAFT_REPO_ROOT:-$PWD}; out=$root/gpurun_out/prof_${tag}_${name}; mkdir -p $out
 if [ $# -eq 0 ]; then
-  long=(python3 $root/bench.py --workload $name --steps 5 --warmup 2 --no-cpu-baseline)
-  short=(python3 $root/bench.py --workload $name --steps 2 --warmup 1 --no-cpu-baseline)
+  long=(python3 $root/bench.py --workload $name --steps 5 --warmup 2 --no-cpu-baseline --no-other-labels)
+  short=(python3 $root/bench.py --workload $name --steps 2 --warmup 1 --no-cpu-baseline --no-other-labels)
 else
   prog=$1; shift
   case $prog in /*) ;; *) prog=$root/$prog ;; esac      # the passes run from /tmp
