@@ -29,21 +29,21 @@ SIGNATURES = {
     "dgnn_debug_last_kernel_ms": (_i, [_i, _vp]),
     "dgnn_debug_last_kernel_name": (ctypes.c_char_p, [_i]),
     "dgnn_gat_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "dgnn_gat_forward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp, _sz, _vp]),
+    "dgnn_gat_forward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 11 + [_vp, _sz, _vp]),
     "dgnn_gat_forward_noalloc": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp]),
     "dgnn_gat_inference": (_i, [_i, _i, _i, _i, _f] + [_vp] * 6 + [_vp, _sz, _vp]),
     "dgnn_gat_forward_tiles_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_gat_forward_tiles": (_i, [_i, _i, _i, _i, _f] + [_vp] * 6 + [_i, _i] + [_vp] * 3 + [_vp, _sz, _vp]),
     "dgnn_gat_row_dot": (_i, [_i, _i, _i] + [_vp] * 3 + [_vp]),
     "dgnn_gat_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 17 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 19 + [_vp, _sz, _vp]),
     "dgnn_gat_backward_packed": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 13 + [_vp, _sz, _vp]),
     "dgnn_dropout_mask": (_i, [_i, _i, _u64, _u64, _vp, _vp]),
     "dgnn_pack_rows": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
-    "dgnn_gat_forward_seeded": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_u64, _u64] + [_vp] * 3 + [_vp, _sz, _vp]),
-    "dgnn_gat_backward_seeded": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_u64, _u64] + [_vp] * 9 + [_vp, _sz, _vp]),
-    "dgnn_gat_forward_seeded_dev": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_vp] + [_vp] * 3 + [_vp, _sz, _vp]),
-    "dgnn_gat_backward_seeded_dev": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_vp] + [_vp] * 9 + [_vp, _sz, _vp]),
+    "dgnn_gat_forward_seeded": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_u64, _u64] + [_vp] * 5 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward_seeded": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_u64, _u64] + [_vp] * 11 + [_vp, _sz, _vp]),
+    "dgnn_gat_forward_seeded_dev": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_vp] + [_vp] * 5 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward_seeded_dev": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_vp] + [_vp] * 11 + [_vp, _sz, _vp]),
     "dgnn_spmm_csr_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_spmm_csr": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_mhsddmm": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp]),

@@ -43,6 +43,11 @@ struct BwdParams {
   const float *attn_row, *attn_col, *edge_max, *edge_sum, *edge_mask;
   const float *in_feat, *grad, *out_feat;
   DropRng rng;         // dropout mask regenerated from (seed, offset) instead of edge_mask
+  // optional pair from the forward (GatherParams::out_neg / a_neg): with it k_bwd_rowstat writes
+  //   grad_attn_row[r,h] = (1 - slope) (S[r,h] * a_neg[r,h] - <grad[r,h,:], out_neg[r,h,:]>)
+  // itself, and the column pass neither scatters d_i to dE nor is followed by the per-row sums
+  const float *out_neg, *a_neg;
+  float *grad_attn_row;
   const float *S_in;   // optional precomputed row dots [m,H]
   float4 *rowstat;     // [m][H] {attn_row, edge_max, edge_sum, S}
   float *dE;           // [nnz][H] in CSR order
@@ -116,10 +121,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
   if (r >= P.m) return;
   for (int hb = 0; hb < P.H; hb += P.hpp) {
     const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
-    float s = 0.f;
+    float s = 0.f, gn = 0.f;
+    vec_t g = VecT<VEC>::zero();
+    if (ln.active && (P.S_in == nullptr || P.out_neg != nullptr)) g = *(const vec_t *)(P.grad + (size_t)r * P.HF + ln.off);
     if (P.S_in == nullptr) {
       if (ln.active) {
-        const vec_t g = *(const vec_t *)(P.grad + (size_t)r * P.HF + ln.off);
         const vec_t o = *(const vec_t *)(P.out_feat + (size_t)r * P.HF + ln.off);
         s = vec_dot<VEC>(g, o);
       }
@@ -127,9 +133,17 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
     } else if (ln.active) {
       s = P.S_in[(size_t)r * P.H + ln.head];
     }
+    if (P.out_neg != nullptr) {
+      if (ln.active) {
+        const vec_t o = *(const vec_t *)(P.out_neg + (size_t)r * P.HF + ln.off);
+        gn = vec_dot<VEC>(g, o);
+      }
+      gn = group_reduce(gn, P.fv, OpSum());
+    }
     if (ln.leader) {
       const size_t i = (size_t)r * P.H + ln.head;
       P.rowstat[i] = make_float4(P.attn_row[i], P.edge_max[i], P.edge_sum[i], s);
+      if (P.out_neg != nullptr) P.grad_attn_row[i] = (1.f - P.slope) * fmaf(s, P.a_neg[i], -gn);
     }
   }
 }
@@ -562,6 +576,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   wave_lds_sync();
 
   // ---------------------------------------------------------------- d_i to CSR order
+  if (P.dE == nullptr) return;      // grad_attn_row came out of the row pass (out_neg / a_neg given)
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
     const int p = j * DGNN_WAVE + lane;

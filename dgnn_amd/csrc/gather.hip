@@ -54,15 +54,18 @@ inline void timer_mark(int which, int edge, hipStream_t st) {
 
 // ----------------------------------------------------------------------------- forward side
 struct FwdLayout {
-  int L, T, slot_stride;
+  int L, T, slot_stride, slot_neg;
   size_t off_rows, off_slots, total;
 };
 
-FwdLayout fwd_layout(int nnz, int h, int f) {
+// neg: partial slots also hold the negative-score aggregate and weight sum (GatherParams::out_neg)
+FwdLayout fwd_layout(int nnz, int h, int f, bool neg = false) {
   FwdLayout w;
   w.L = fast_group_size(h, nnz, narrow_rows(h, f));
   w.T = (nnz + w.L - 1) / w.L;
-  w.slot_stride = (int)align_up((size_t)h * f + 2 * (size_t)h, 4);
+  w.slot_neg = (int)align_up((size_t)h * f + 3 * (size_t)h, 4);
+  w.slot_stride = neg ? (int)align_up((size_t)w.slot_neg + (size_t)h * f, 4)
+                      : (int)align_up((size_t)h * f + 2 * (size_t)h, 4);
   size_t o = 0;
   w.off_rows = o;
   o += align_up(sizeof(int) * (size_t)(w.T > 0 ? w.T : 1), 256);
@@ -76,17 +79,21 @@ bool fwd_fast_ok(int m, int h) { return h <= DGNN_FAST_HMAX && m < (1 << 30) && 
 
 template <int MODE>
 int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, hipStream_t st) {
-  const FwdLayout w = fwd_layout(P.nnz, P.H, P.F);
+  const bool neg = MODE == MODE_GAT && P.out_neg != nullptr;
+  const FwdLayout w = fwd_layout(P.nnz, P.H, P.F, neg);
   if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
   P.HF = P.H * P.F;
   P.L = w.L;
   P.T = w.T;
   P.slot_stride = w.slot_stride;
+  P.slot_neg = w.slot_neg;
   P.task_row0 = (int *)((char *)workspace + w.off_rows);
   P.slots = (float *)((char *)workspace + w.off_slots);
   const bool vec4 = (P.F % 4 == 0) && aligned16(P.in_feat) && aligned16(P.out);
   const bool attn_ok = (MODE != MODE_GAT) || P.H != 4 || aligned16(P.attn_col);
   if (!attn_ok) return DGNN_ERR_ALIGNMENT;
+  // the negative-score pair exists for float4 rows only (the caller falls back to the edge-gradient path)
+  if (neg && !(vec4 && aligned16(P.out_neg) && aligned16(P.a_neg))) return DGNN_ERR_UNSUPPORTED;
   P.rowv = vec4 ? P.HF / 4 : P.HF;
   // rows narrower than one wave of float4 slots are bound by instructions per edge, not bandwidth
   // (the STEADY instantiation of the kernel; DGNN_FWD_STEADY=0 switches it off for A/B runs)
@@ -117,7 +124,11 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
     if (MODE == MODE_GAT && timing_on())                                                       \
       std::snprintf(g_timer.name[0], sizeof(g_timer.name[0]), "k_fast_row_gather<%d, %d, %d, %d, %s>", MODE, VECV, \
                     NSV, HTV, STV ? "true" : "false");                                         \
-    hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV, STV>), grid, dim3(DGNN_BLOCK), lds, st, P); \
+    if (MODE == MODE_GAT && VECV == 4 && neg)                                                  \
+      hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV, STV, (MODE == MODE_GAT && VECV == 4)>), grid, \
+                         dim3(DGNN_BLOCK), lds, st, P);                                        \
+    else                                                                                       \
+      hipLaunchKernelGGL((k_fast_row_gather<MODE, VECV, NSV, HTV, STV>), grid, dim3(DGNN_BLOCK), lds, st, P); \
   }
 #define DGNN_FWD_CASES(HTV)                                                                    \
   DGNN_FWD_CASE(4, 1, HTV, true)                                                               \
@@ -142,8 +153,11 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
                    const float *attn_row, const float *attn_col, const int *row_ptr,
                    const int *col_ind, const float *in_feat, const float *edge_mask,
                    float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                   size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0, nullptr}) {
+                   size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0, nullptr},
+                   float *out_neg = nullptr, float *a_neg = nullptr) {
   if (m == 0) return DGNN_OK;
+  if ((out_neg == nullptr) != (a_neg == nullptr)) return DGNN_ERR_BAD_ARG;
+  if (out_neg != nullptr && (!edge_max || !edge_sum)) return DGNN_ERR_BAD_ARG;
   // the H == 4 kernels move the per-row / per-edge scalars as float4
   const bool h4_aligned = aligned16(attn_col) && aligned16(attn_row) && aligned16(edge_mask) &&
                           aligned16(edge_max) && aligned16(edge_sum);
@@ -154,8 +168,10 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
     P.row_ptr = row_ptr; P.col_ind = col_ind;
     P.attn_row = attn_row; P.attn_col = attn_col; P.edge_mask = edge_mask; P.rng = rng;
     P.in_feat = in_feat; P.edge_max = edge_max; P.edge_sum = edge_sum; P.out = out_feat;
+    P.out_neg = out_neg; P.a_neg = a_neg;
     return launch_fast_gather<MODE_GAT>(P, workspace, workspace_bytes, st);
   }
+  if (out_neg != nullptr) return DGNN_ERR_UNSUPPORTED;   // the wave-per-row kernels have no negative-score pair
   if (rng.on) return DGNN_ERR_UNSUPPORTED;   // the wave-per-row kernels read a materialised mask
   hipLaunchKernelGGL(k_gat_fwd_row, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, m, h, f,
                      attn_drop, slope, attn_row, attn_col, row_ptr, col_ind, in_feat, edge_mask,
@@ -285,14 +301,14 @@ const char *dgnn_debug_last_kernel_name(int which) {
 
 size_t dgnn_gat_forward_workspace_bytes(int m, int nnz, int h, int f) {
   if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
-  return fwd_layout(nnz, h, f).total;
+  return fwd_layout(nnz, h, f, true).total;      // enough with or without the out_neg / a_neg pair
 }
 
 int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
                      const float *attn_row, const float *attn_col, const int *row_ptr,
                      const int *col_ind, const float *in_feat, const float *edge_mask,
-                     float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                     size_t workspace_bytes, void *stream) {
+                     float *edge_max, float *edge_sum, float *out_feat, float *out_neg, float *a_neg,
+                     void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (m == 0) return DGNN_OK;                          // nothing to write
@@ -301,11 +317,12 @@ int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negati
   if (nnz > 0 && !col_ind) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
   if (attn_drop > 0.f && nnz > 0 && !edge_mask) return DGNN_ERR_BAD_ARG;
-  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+  if (!workspace || workspace_bytes < fwd_layout(nnz, h, f, out_neg != nullptr).total)
     return DGNN_ERR_WORKSPACE;
   return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
                         col_ind, in_feat, attn_drop > 0.f ? edge_mask : nullptr, edge_max, edge_sum,
-                        out_feat, workspace, workspace_bytes, (hipStream_t)stream);
+                        out_feat, workspace, workspace_bytes, (hipStream_t)stream, DropRng{0, 0, 0, nullptr},
+                        out_neg, a_neg);
 }
 
 // ------------------------------------------------------------ entry point that allocates nothing
@@ -353,7 +370,7 @@ int dgnn_gat_forward_noalloc(int m, int nnz, int h, int f, float attn_drop, floa
   // The kernels write every slot and every task_row0 entry they later read (each group holds at
   // least one edge, hence one row), so nothing of the previous call's contents needs clearing.
   return dgnn_gat_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr,
-                          col_ind, in_feat, edge_mask, edge_max, edge_sum, out_feat, ptr,
+                          col_ind, in_feat, edge_mask, edge_max, edge_sum, out_feat, nullptr, nullptr, ptr,
                           (size_t)DGNN_NOALLOC_SCRATCH_BYTES, stream);
 }
 
@@ -367,8 +384,7 @@ int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope, const
   if (!attn_row || !row_ptr || !out_feat) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && (!attn_col || !in_feat)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && !col_ind) return DGNN_ERR_BAD_ARG;
-  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
-    return DGNN_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < fwd_layout(nnz, h, f).total) return DGNN_ERR_WORKSPACE;
   return launch_forward(m, nnz, h, f, 0.f, negative_slope, attn_row, attn_col, row_ptr, col_ind,
                         in_feat, nullptr, nullptr, nullptr, out_feat, workspace, workspace_bytes,
                         (hipStream_t)stream);
@@ -376,7 +392,7 @@ int dgnn_gat_inference(int m, int nnz, int h, int f, float negative_slope, const
 
 size_t dgnn_gat_forward_tiles_workspace_bytes(int m, int nnz, int h, int f) {
   if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
-  return align_up(fwd_layout(nnz, h, f).total, 256) + 256;   // + the validation flag
+  return align_up(fwd_layout(nnz, h, f, true).total, 256) + 256;   // + the validation flag
 }
 
 }  // extern "C"
@@ -426,7 +442,7 @@ int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
   if (rc) return rc;
   if (tile_nnz <= 0) return DGNN_ERR_BAD_ARG;
   if (n_tiles < 0 || (n_tiles > 0 && !tile_scheduler) || (m > 0 && !row_ptr)) return DGNN_ERR_BAD_ARG;
-  const size_t fwd_bytes = align_up(fwd_layout(nnz, h, f).total, 256);
+  const size_t fwd_bytes = align_up(fwd_layout(nnz, h, f, true).total, 256);
   if (!workspace || workspace_bytes < fwd_bytes + 256) return DGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int *flag = (int *)((char *)workspace + fwd_bytes);
@@ -442,7 +458,8 @@ int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
   if (e != hipSuccess) return (int)e;
   if (host_flag != 0) return DGNN_ERR_BAD_ARG;
   return dgnn_gat_forward(m, nnz, h, f, 0.f, negative_slope, attn_row, attn_col, row_ptr, col_ind,
-                          in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, fwd_bytes, stream);
+                          in_feat, nullptr, edge_max, edge_sum, out_feat, nullptr, nullptr, workspace, fwd_bytes,
+                          stream);
 }
 
 int dgnn_gat_row_dot(int m, int h, int f, const float *grad, const float *out_feat,
@@ -474,7 +491,9 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
                              const float *out_feat, const float *row_dot, const float4 *packed,
                              float *grad_feat, float *grad_attn_row, float *grad_attn_col,
                              void *workspace, size_t workspace_bytes, void *stream,
-                             DropRng rng = DropRng{0, 0, 0, nullptr}) {
+                             DropRng rng = DropRng{0, 0, 0, nullptr}, const float *out_neg = nullptr,
+                             const float *a_neg = nullptr) {
+  if ((out_neg == nullptr) != (a_neg == nullptr)) return DGNN_ERR_BAD_ARG;
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (n < 0) return DGNN_ERR_BAD_ARG;
@@ -510,6 +529,9 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
               (vec == 1 || (aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
                             (out == nullptr || aligned16(out))));
   if (packed != nullptr && !(fast && aligned16(packed))) return DGNN_ERR_UNSUPPORTED;
+  // grad_attn_row from the forward's negative-score pair (row pass) instead of the [nnz,h] edge
+  // gradients: the fast float4 kernels with the unpacked per-row inputs
+  const bool neg = fast && vec == 4 && out_neg != nullptr && packed == nullptr && m > 0 && aligned16(out_neg);
   if (rng.on && !fast) return DGNN_ERR_UNSUPPORTED;   // the wave-per-column kernel reads a materialised mask
   if (fast) {
     BwdParams P = {};
@@ -524,8 +546,9 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.attn_row = attn_row; P.attn_col = attn_col; P.edge_max = edge_max; P.edge_sum = edge_sum;
     P.edge_mask = mask; P.rng = rng; P.in_feat = in_feat; P.grad = grad; P.out_feat = out;
     P.S_in = row_dot;
+    P.out_neg = neg ? out_neg : nullptr; P.a_neg = neg ? a_neg : nullptr; P.grad_attn_row = grad_attn_row;
     P.rowstat = packed ? const_cast<float4 *>(packed) : (float4 *)(ws + w.off_stat);
-    P.dE = dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
+    P.dE = neg ? nullptr : dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
     P.task_col0 = (int *)(ws + w.off_cols);
     P.slots = (float *)(ws + w.off_slots);
     if (m > 0 && !packed) {
@@ -571,7 +594,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
       DGNN_LAUNCH_CHECK();
     }
   }
-  if (m > 0) {
+  if (m > 0 && !neg) {
     int *long_count = (int *)(ws + w.off_long);
     hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
@@ -612,13 +635,13 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
                       const int *row_ind, const int *permute, const float *edge_max,
                       const float *edge_sum, const float *edge_mask, const float *in_feat,
                       const float *attn_row, const float *attn_col, const float *grad,
-                      const float *out_feat, const float *row_dot, float *grad_feat,
-                      float *grad_attn_row, float *grad_attn_col, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+                      const float *out_feat, const float *row_dot, const float *out_neg,
+                      const float *a_neg, float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                      void *workspace, size_t workspace_bytes, void *stream) {
   return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
                            permute, edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad, out_feat,
                            row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
-                           workspace_bytes, stream);
+                           workspace_bytes, stream, DropRng{0, 0, 0, nullptr}, out_neg, a_neg);
 }
 
 int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
@@ -663,26 +686,27 @@ int dgnn_dropout_mask(int nnz, int h, uint64_t seed, uint64_t offset, float *mas
 int dgnn_gat_forward_seeded(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
                             const float *attn_row, const float *attn_col, const int *row_ptr,
                             const int *col_ind, const float *in_feat, uint64_t seed, uint64_t offset,
-                            float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                            size_t workspace_bytes, void *stream) {
+                            float *edge_max, float *edge_sum, float *out_feat, float *out_neg,
+                            float *a_neg, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (m == 0) return DGNN_OK;
   if (!attn_row || !row_ptr || !out_feat || !edge_max || !edge_sum) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && (!attn_col || !in_feat || !col_ind)) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
-  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+  if (!workspace || workspace_bytes < fwd_layout(nnz, h, f, out_neg != nullptr).total)
     return DGNN_ERR_WORKSPACE;
   return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr, col_ind,
                         in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, workspace_bytes,
-                        (hipStream_t)stream, DropRng{seed, offset, attn_drop > 0.f ? 1 : 0, nullptr});
+                        (hipStream_t)stream, DropRng{seed, offset, attn_drop > 0.f ? 1 : 0, nullptr}, out_neg,
+                        a_neg);
 }
 
 int dgnn_gat_forward_seeded_dev(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
                                 const float *attn_row, const float *attn_col, const int *row_ptr,
                                 const int *col_ind, const float *in_feat, const uint64_t *rng_state,
-                                float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+                                float *edge_max, float *edge_sum, float *out_feat, float *out_neg,
+                                float *a_neg, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = check_dims(m, nnz, h, f);
   if (rc) return rc;
   if (m == 0) return DGNN_OK;
@@ -690,12 +714,13 @@ int dgnn_gat_forward_seeded_dev(int m, int nnz, int h, int f, float attn_drop, f
   if (nnz > 0 && (!attn_col || !in_feat || !col_ind)) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
   if (attn_drop > 0.f && (!rng_state || ((uintptr_t)rng_state & 7u))) return DGNN_ERR_BAD_ARG;
-  if (!workspace || workspace_bytes < dgnn_gat_forward_workspace_bytes(m, nnz, h, f))
+  if (!workspace || workspace_bytes < fwd_layout(nnz, h, f, out_neg != nullptr).total)
     return DGNN_ERR_WORKSPACE;
   return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr, col_ind,
                         in_feat, nullptr, edge_max, edge_sum, out_feat, workspace, workspace_bytes,
                         (hipStream_t)stream,
-                        DropRng{0, 0, attn_drop > 0.f ? 1 : 0, (const unsigned long long *)rng_state});
+                        DropRng{0, 0, attn_drop > 0.f ? 1 : 0, (const unsigned long long *)rng_state}, out_neg,
+                        a_neg);
 }
 
 int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float negative_slope,
@@ -704,6 +729,7 @@ int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float nega
                                  const float *edge_max, const float *edge_sum, const uint64_t *rng_state,
                                  const float *in_feat, const float *attn_row, const float *attn_col,
                                  const float *grad, const float *out_feat, const float *row_dot,
+                                 const float *out_neg, const float *a_neg,
                                  float *grad_feat, float *grad_attn_row, float *grad_attn_col,
                                  void *workspace, size_t workspace_bytes, void *stream) {
   if (attn_drop > 0.f && (!rng_state || ((uintptr_t)rng_state & 7u))) return DGNN_ERR_BAD_ARG;
@@ -711,7 +737,7 @@ int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float nega
                            permute, edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, out_feat,
                            row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
                            workspace_bytes, stream,
-                           DropRng{0, 0, 1, (const unsigned long long *)rng_state});
+                           DropRng{0, 0, 1, (const unsigned long long *)rng_state}, out_neg, a_neg);
 }
 
 int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative_slope,
@@ -720,13 +746,13 @@ int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative
                              const float *edge_max, const float *edge_sum, uint64_t seed,
                              uint64_t offset, const float *in_feat, const float *attn_row,
                              const float *attn_col, const float *grad, const float *out_feat,
-                             const float *row_dot, float *grad_feat, float *grad_attn_row,
-                             float *grad_attn_col, void *workspace, size_t workspace_bytes,
-                             void *stream) {
+                             const float *row_dot, const float *out_neg, const float *a_neg,
+                             float *grad_feat, float *grad_attn_row, float *grad_attn_col, void *workspace,
+                             size_t workspace_bytes, void *stream) {
   return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind,
                            permute, edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, out_feat,
                            row_dot, nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace,
-                           workspace_bytes, stream, DropRng{seed, offset, 1, nullptr});
+                           workspace_bytes, stream, DropRng{seed, offset, 1, nullptr}, out_neg, a_neg);
 }
 
 // ------------------------------------------------------------------------- GE-SpMM / GMM

@@ -58,6 +58,13 @@ struct GatherParams {
   const float *in_feat;
   float *edge_max, *edge_sum;        // GAT stats or NULL
   float *out;
+  // GAT, optional pair (the NEG instantiation): what lets the backward compute grad_attn_row per
+  // row, without the [nnz,H] edge-gradient round trip.  With sl_j = (e_j < 0 ? slope : 1):
+  //   grad_attn_row = sum_j a_j (g_j - S) sl_j = (1 - slope) (S * A_neg - <grad, out_neg>)
+  // because sum_j a_j g_j sl_j = S - (1-slope) sum_{e_j<0} a_j g_j and sum_j a_j sl_j = 1 - (1-slope) A_neg.
+  float *out_neg;                    // [m,H,F]  sum over the edges with e_j < 0 of w_j * in_feat[c_j]
+  float *a_neg;                      // [m,H]    sum over the edges with e_j < 0 of the softmax weight (no mask)
+  int slot_neg;                      // float offset of the out_neg partial inside a slot
   int *task_row0;                    // [T] row that contains edge t*L
   float *slots;                      // [2T][slot_stride]
 };
@@ -119,6 +126,10 @@ __global__ void k_fast_prep_rows(GatherParams P) {
       const int width = P.sum_heads ? P.F : P.HF;
       float *o = P.out + (size_t)r * width;
       for (int i = 0; i < width; ++i) o[i] = 0.f;
+      if (P.out_neg != nullptr) {
+        for (int i = 0; i < P.HF; ++i) P.out_neg[(size_t)r * P.HF + i] = 0.f;
+        for (int h = 0; h < P.H; ++h) P.a_neg[(size_t)r * P.H + h] = 0.f;
+      }
       if (P.edge_max != nullptr)
         for (int h = 0; h < P.H; ++h) {
           P.edge_max[(size_t)r * P.H + h] = DGNN_NEG_INIT;
@@ -188,6 +199,20 @@ __device__ __forceinline__ void st_heads(float *p, const float (&d)[HT]) {
   }
 }
 
+// One edge into the accumulator(s).  NEG: the staged weight carries the sign bit of its score; the
+// plain aggregate takes |w|, the negative-score aggregate takes |w| only where the bit is set.
+template <bool NEG, int VEC>
+__device__ __forceinline__ void acc_edge(typename VecT<VEC>::type &acc, typename VecT<VEC>::type &accn, float w,
+                                         const typename VecT<VEC>::type &x) {
+  if constexpr (NEG) {
+    const float wa = fabsf(w);
+    VecT<VEC>::fma(acc, wa, x);
+    VecT<VEC>::fma(accn, (__float_as_uint(w) & 0x80000000u) ? wa : 0.f, x);
+  } else {
+    VecT<VEC>::fma(acc, w, x);
+  }
+}
+
 // Store of a finished WHOLE row when the output is the sum over heads (P.sum_heads; float4 lanes, one
 // slot per lane): the lane of head 0 that owns feature slot fs adds the accumulators of the lanes
 // that own the same slot of heads 1 .. H-1 (they sit F/4 lanes apart) and writes out[row, fs].
@@ -211,7 +236,9 @@ __device__ __forceinline__ void store_row_summed(const GatherParams &P, int row,
 // STEADY: the instantiation for narrow rows (fewer than 64 float4 slots), whose gather loop is
 // bound by instructions per edge: it adds an unguarded steady-state loop (phase C).  Wide rows
 // keep the kernel without it (the extra path costs the 4 x 64 kernel 10 % through registers).
-template <int MODE, int VEC, int NS, int HT, bool STEADY>
+// NEG (GAT only, float4 rows): also produce out_neg / a_neg (GatherParams); the weight staged in LDS
+// carries the sign bit of its score (weights are >= 0, so the bit is free).
+template <int MODE, int VEC, int NS, int HT, bool STEADY, bool NEG = false>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) {
   constexpr int HTA = HT > 0 ? HT : 1;     // array extent that is legal for HT == 0 too
   using V = VecT<VEC>;
@@ -311,6 +338,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           for (int h = 0; h < HTA; ++h) pe[h] = live ? expf(e[h] - mx[h]) : 0.f;
 #pragma unroll
           for (int h = 0; h < HTA; ++h) sm[h] = wave_sum(pe[h]);
+          float an[HTA];
+          if constexpr (NEG) {
+#pragma unroll
+            for (int h = 0; h < HTA; ++h) {
+              an[h] = wave_sum((live && e[h] < 0.f) ? pe[h] : 0.f);
+              if (whole) an[h] = an[h] / sm[h];
+            }
+          }
           if (live) {
             float w[HTA];
 #pragma unroll
@@ -329,6 +364,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
               }
             }
+            if constexpr (NEG) {
+#pragma unroll
+              for (int h = 0; h < HTA; ++h)
+                if (e[h] < 0.f) w[h] = -w[h];
+            }
             st_heads<HTA>(sc + (size_t)p * HTA, w);
           }
           if (lane == 0) {
@@ -337,9 +377,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 st_heads<HTA>(P.edge_max + (size_t)r * HTA, mx);
                 st_heads<HTA>(P.edge_sum + (size_t)r * HTA, sm);
               }
+              if constexpr (NEG) st_heads<HTA>(P.a_neg + (size_t)r * HTA, an);
             } else {
               st_heads<HTA>(slot_ptr + P.HF, mx);
               st_heads<HTA>(slot_ptr + P.HF + HTA, sm);
+              if constexpr (NEG) st_heads<HTA>(slot_ptr + P.HF + 2 * HTA, an);
             }
           }
         } else if (MODE == MODE_GAT && H == 4 && (b - a) <= DGNN_WAVE) {
@@ -369,6 +411,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           }
           float4 sm;
           sm.x = wave_sum(pe.x); sm.y = wave_sum(pe.y); sm.z = wave_sum(pe.z); sm.w = wave_sum(pe.w);
+          float4 an4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (NEG) {
+            an4.x = wave_sum(e4.x < 0.f ? pe.x : 0.f); an4.y = wave_sum(e4.y < 0.f ? pe.y : 0.f);
+            an4.z = wave_sum(e4.z < 0.f ? pe.z : 0.f); an4.w = wave_sum(e4.w < 0.f ? pe.w : 0.f);
+            if (whole) { an4.x /= sm.x; an4.y /= sm.y; an4.z /= sm.z; an4.w /= sm.w; }
+          }
           if (live) {
             float4 w4 = pe;
             if (whole) { w4.x /= sm.x; w4.y /= sm.y; w4.z /= sm.z; w4.w /= sm.w; }   // :102
@@ -382,6 +430,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
               w4.x = drop_scale(w4.x, P.attn_drop); w4.y = drop_scale(w4.y, P.attn_drop);  // :104
               w4.z = drop_scale(w4.z, P.attn_drop); w4.w = drop_scale(w4.w, P.attn_drop);
             }
+            if constexpr (NEG) {
+              if (e4.x < 0.f) w4.x = -w4.x;
+              if (e4.y < 0.f) w4.y = -w4.y;
+              if (e4.z < 0.f) w4.z = -w4.z;
+              if (e4.w < 0.f) w4.w = -w4.w;
+            }
             *(float4 *)(sc + (size_t)p * 4) = w4;
           }
           if (lane == 0) {
@@ -390,9 +444,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 *(float4 *)(P.edge_max + (size_t)r * 4) = mx;
                 *(float4 *)(P.edge_sum + (size_t)r * 4) = sm;
               }
+              if constexpr (NEG) *(float4 *)(P.a_neg + (size_t)r * 4) = an4;
             } else {
               *(float4 *)(slot_ptr + P.HF) = mx;
               *(float4 *)(slot_ptr + P.HF + 4) = sm;
+              if constexpr (NEG) *(float4 *)(slot_ptr + P.HF + 8) = an4;
             }
           }
         } else if (MODE == MODE_GAT) {
@@ -402,15 +458,23 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             for (int p = a + lane; p < b; p += DGNN_WAVE)
               mx = fmaxf(mx, leaky_relu(arh + sc[(size_t)p * H + h], P.slope));
             mx = wave_max(mx);
-            float sm = 0.f;
+            float sm = 0.f, an = 0.f;
             for (int p = a + lane; p < b; p += DGNN_WAVE) {
-              const float pe = expf(leaky_relu(arh + sc[(size_t)p * H + h], P.slope) - mx);
-              sc[(size_t)p * H + h] = pe;
+              const float ev = leaky_relu(arh + sc[(size_t)p * H + h], P.slope);
+              const float pe = expf(ev - mx);
+              sc[(size_t)p * H + h] = (NEG && ev < 0.f) ? -pe : pe;      // NEG: sign bit = (score < 0)
               sm += pe;
+              if (NEG && ev < 0.f) an += pe;
             }
             sm = wave_sum(sm);
+            if constexpr (NEG) {
+              an = wave_sum(an);
+              if (whole) an = an / sm;
+            }
             for (int p = a + lane; p < b; p += DGNN_WAVE) {
               float w = sc[(size_t)p * H + h];
+              const bool ng = NEG && (__float_as_uint(w) & 0x80000000u) != 0u;
+              if constexpr (NEG) w = fabsf(w);
               if (whole) w = w / sm;                       // exp(e-max)/sum per edge, :102
               if (P.edge_mask != nullptr || P.rng.on) {
                 const float mk = P.rng.on ? drop_uniform(P.rng, (unsigned long long)(e0 + p) * H + h)
@@ -418,7 +482,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 if (!(mk > P.attn_drop)) w = 0.f;   // :95
                 w = drop_scale(w, P.attn_drop);                                       // :104
               }
-              sc[(size_t)p * H + h] = w;
+              sc[(size_t)p * H + h] = ng ? -w : w;
             }
             if (lane == 0) {
               if (whole) {
@@ -426,9 +490,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                   P.edge_max[(size_t)r * H + h] = mx;
                   P.edge_sum[(size_t)r * H + h] = sm;
                 }
+                if constexpr (NEG) P.a_neg[(size_t)r * H + h] = an;
               } else {
                 slot_ptr[P.HF + h] = mx;
                 slot_ptr[P.HF + H + h] = sm;
+                if constexpr (NEG) slot_ptr[P.HF + 2 * H + h] = an;
               }
             }
           }
@@ -474,7 +540,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       const int head = active ? (sl * 4) / P.F : 0;
       const size_t lane_off = (size_t)(active ? sl : 0) * 4;
       const float *wbase = sc + head;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accn = acc;
       float4 ring[DGNN_FAST_U];
       float wring[DGNN_FAST_U];
       int q = 0;
@@ -488,13 +554,19 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         x = *(const float4 *)(P.in_feat + (size_t)c * P.HF + lane_off);
       };
       auto consume = [&](const float4 &x, float w, int j) {
-        V::fma(acc, w, x);
+        acc_edge<NEG, 4>(acc, accn, w, x);
         if (uniform_i32((int)steps[j]) & (int)DGNN_PACK_END) {
           for (int off = S; off < DGNN_WAVE; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
             acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
             acc.z += __shfl_xor(acc.z, off, DGNN_WAVE);
             acc.w += __shfl_xor(acc.w, off, DGNN_WAVE);
+            if constexpr (NEG) {
+              accn.x += __shfl_xor(accn.x, off, DGNN_WAVE);
+              accn.y += __shfl_xor(accn.y, off, DGNN_WAVE);
+              accn.z += __shfl_xor(accn.z, off, DGNN_WAVE);
+              accn.w += __shfl_xor(accn.w, off, DGNN_WAVE);
+            }
           }
           const int d = uniform_i32(dq[q]);
           ++q;
@@ -503,6 +575,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           } else {
             float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
             if (active && g == 0) *(float4 *)(dst + lane_off) = acc;
+            if constexpr (NEG) {
+              float *dn = (d >= 0) ? P.out_neg + (size_t)d * P.HF
+                                   : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
+              if (active && g == 0) *(float4 *)(dn + lane_off) = accn;
+              accn = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
           }
           acc = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -557,7 +635,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     bool active[NS];
     size_t lane_off[NS];
     const float *wbase[NS];
-    vec_t acc[NS];
+    vec_t acc[NS], accn[NS];
     vec_t ring[DGNN_FAST_U][NS];
     float wring[DGNN_FAST_U][NS];
     int hd0 = 0;                           // head of the lane's first slot (summed store)
@@ -569,6 +647,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       lane_off[s] = (size_t)(active[s] ? vslot : 0) * VEC;
       wbase[s] = sc + head;
       acc[s] = V::zero();
+      accn[s] = V::zero();
       if (s == 0) hd0 = head;
     }
     int q = 0;
@@ -577,7 +656,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     // One edge of the stream: accumulate (w, x) and flush at a row end.
     auto consume = [&](const vec_t (&x)[NS], const float (&w)[NS], unsigned ci) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) V::fma(acc[s], w[s], x[s]);
+      for (int s = 0; s < NS; ++s) acc_edge<NEG, VEC>(acc[s], accn[s], w[s], x[s]);
       if (ci & DGNN_ROWEND) {
         const int d = uniform_i32(dq[q]);
         ++q;
@@ -593,6 +672,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         for (int s = 0; s < NS; ++s) {
           if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
           acc[s] = V::zero();
+        }
+        if constexpr (NEG) {
+          float *dn = (d >= 0) ? P.out_neg + (size_t)d * P.HF
+                               : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            if (active[s]) *(vec_t *)(dn + lane_off[s]) = accn[s];
+            accn[s] = V::zero();
+          }
         }
       }
     };
@@ -706,7 +794,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
               }
             }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) V::fma(acc[s], w[s], x[s]);
+            for (int s = 0; s < NS; ++s) acc_edge<NEG, VEC>(acc[s], accn[s], w[s], x[s]);
             if (ci & DGNN_ROWEND) {
               const int d = uniform_i32(dq[q]);
               ++q;
@@ -725,6 +813,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 for (int s = 0; s < NS; ++s) {
                   if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
                   acc[s] = V::zero();
+                }
+                if constexpr (NEG) {
+                  float *dn = (d >= 0) ? P.out_neg + (size_t)d * P.HF
+                                       : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
+#pragma unroll
+                  for (int s = 0; s < NS; ++s) {
+                    if (active[s]) *(vec_t *)(dn + lane_off[s]) = accn[s];
+                    accn[s] = V::zero();
+                  }
                 }
               }
             }
@@ -797,6 +894,22 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
             acc[0] = fmaf(v[j].x, fct, acc[0]); acc[1] = fmaf(v[j].y, fct, acc[1]);
             acc[2] = fmaf(v[j].z, fct, acc[2]); acc[3] = fmaf(v[j].w, fct, acc[3]);
           }
+      }
+      if (P.out_neg != nullptr) {
+        // the negative-score aggregate and weight sum of the cut row: same merge (float4 rows only)
+        float an = 0.f, nacc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < npieces; ++i) {
+          const float *sp = slot_of(i);
+          const float fct = expf(sp[P.HF + head] - M);
+          const float4 v = *(const float4 *)(sp + P.slot_neg + fid);
+          an = fmaf(sp[P.HF + 2 * H + head], fct, an);
+          nacc[0] = fmaf(v.x, fct, nacc[0]); nacc[1] = fmaf(v.y, fct, nacc[1]);
+          nacc[2] = fmaf(v.z, fct, nacc[2]); nacc[3] = fmaf(v.w, fct, nacc[3]);
+        }
+        if (active) {
+          *(float4 *)(P.out_neg + (size_t)r * P.HF + fid) = make_float4(nacc[0] / S, nacc[1] / S, nacc[2] / S, nacc[3] / S);
+          if (fid == head * P.F) P.a_neg[(size_t)r * H + head] = an / S;
+        }
       }
       if (active) {
         if (vec4)

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_edgeconv_bwd_gather(long long total, in
 
 extern "C" {
 
-int dgnn_abi_version(void) { return 1; }
+int dgnn_abi_version(void) { return 2; }   // 2: out_neg / a_neg in the fused GAT entry points
 
 const char *dgnn_error_string(int code) {
   switch (code) {

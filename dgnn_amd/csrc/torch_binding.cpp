@@ -165,7 +165,7 @@ GatDims check_gat_fwd(const Tensor &attn_row, const Tensor &attn_col, const Tens
 // -> [out_feat, edge_max, edge_sum, edge_mask]   (fused_gatconv.cpp:11-32)
 std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
                                 const Tensor &col_ind, double negative_slope, const Tensor &in_feat,
-                                double attn_drop, const OptTensor &edge_mask_in, const OutList &outs) {
+                                double attn_drop, const OptTensor &edge_mask_in, const OutList &outs, bool neg) {
   const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
   c10::DeviceGuard guard(in_feat.device());
   Tensor out = out_f32(outs, 0, {d.m, d.h, d.f}, in_feat, "out_feat");
@@ -182,10 +182,25 @@ std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, 
   }
   const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
   Tensor ws = workspace(nb, in_feat);
-  check_rc(API(dgnn_gat_forward)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope, fp(attn_row),
+  // neg: also the negative-score pair [out_neg, a_neg] the backward turns into grad_attn_row
+  // (appended to the list; two undefined tensors = None where the kernels have no such pair)
+  Tensor out_neg, a_neg;
+  if (neg && d.m > 0 && d.f % 4 == 0) {
+    out_neg = new_f32({d.m, d.h, d.f}, in_feat);
+    a_neg = new_f32({d.m, d.h}, in_feat);
+  }
+  int rc = API(dgnn_gat_forward)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope, fp(attn_row),
                                  fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), fp(edge_mask), fo(edge_max),
-                                 fo(edge_sum), fo(out), ptr<void>(ws), nb, stream_of(in_feat)),
-           "dgnn_gat_forward");
+                                 fo(edge_sum), fo(out), fo(out_neg), fo(a_neg), ptr<void>(ws), nb, stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED && out_neg.defined()) {
+    out_neg = Tensor();
+    a_neg = Tensor();
+    rc = API(dgnn_gat_forward)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope, fp(attn_row),
+                               fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), fp(edge_mask), fo(edge_max),
+                               fo(edge_sum), fo(out), nullptr, nullptr, ptr<void>(ws), nb, stream_of(in_feat));
+  }
+  check_rc(rc, "dgnn_gat_forward");
+  if (neg) return {out, edge_max, edge_sum, edge_mask, out_neg, a_neg};
   return {out, edge_max, edge_sum, edge_mask};
 }
 
@@ -250,6 +265,15 @@ Tensor gat_row_dot(const Tensor &grad, const Tensor &out_feat) {
   return S;
 }
 
+// the optional (out_neg [m,h,f], a_neg [m,h]) pair of the backward entry points: both or neither
+void check_neg_pair(const OptTensor &out_neg, const OptTensor &a_neg, const Tensor &grad) {
+  if (given(out_neg) != given(a_neg)) fail("out_neg and a_neg come as a pair");
+  if (!given(out_neg)) return;
+  f32(*out_neg, "out_neg", 3), f32(*a_neg, "a_neg", 2);
+  if (out_neg->sizes() != grad.sizes() || a_neg->size(0) != grad.size(0) || a_neg->size(1) != grad.size(1))
+    fail("out_neg must be [m,h,f] like grad, a_neg [m,h]");
+}
+
 // -> [grad_feat, grad_attn_row, grad_attn_col]   (fused_gatconv.cpp:104-166).
 // out_feat / row_dot (keywords, not in the reference signature): the saved forward output, or
 // the precomputed row term; either removes one whole gather pass (include/dgnn_hip.h).  Rows
@@ -259,7 +283,7 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
                                  const Tensor &edge_max, const Tensor &edge_sum, const OptTensor &edge_mask,
                                  const Tensor &in_feat, const Tensor &attn_row, const Tensor &attn_col,
                                  const Tensor &grad, const OptTensor &out_feat, const OptTensor &row_dot,
-                                 const OutList &outs) {
+                                 const OutList &outs, const OptTensor &out_neg, const OptTensor &a_neg) {
   i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
   i32(permute, "permute");
   f32(edge_max, "edge_max", 2), f32(edge_sum, "edge_sum", 2), f32(in_feat, "in_feat", 3);
@@ -267,6 +291,7 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
   const int m = as_int(row_ptr.size(0) - 1, "rows"), nnz = as_int(col_ind.size(0), "nnz");
   const int n = as_int(col_ptr.size(0) - 1, "columns");
   const int h = as_int(in_feat.size(1), "heads"), f = as_int(in_feat.size(2), "features");   // :1049-1050
+  check_neg_pair(out_neg, a_neg, grad);
   if (in_feat.size(0) != n || attn_col.size(0) != n)
     fail("gat_backward: in_feat/attn_col rows must equal len(col_ptr)-1");
   if (grad.size(0) != m || attn_row.size(0) != m || edge_max.size(0) != m || edge_sum.size(0) != m)
@@ -289,8 +314,8 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
   check_rc(API(dgnn_gat_backward)(m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind),
                                   ip(col_ptr), ip(row_ind), ip(permute), fp(edge_max), fp(edge_sum),
                                   attn_drop > 0.0 ? fp(edge_mask) : nullptr, fp(in_feat), fp(attn_row), fp(attn_col),
-                                  fp(grad), fp(out_feat), fp(row_dot), fo(grad_feat), fo(grad_attn_row),
-                                  fo(grad_attn_col), ptr<void>(ws), nb, stream_of(in_feat)),
+                                  fp(grad), fp(out_feat), fp(row_dot), fp(out_neg), fp(a_neg), fo(grad_feat),
+                                  fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb, stream_of(in_feat)),
            "dgnn_gat_backward");
   return {grad_feat, grad_attn_row, grad_attn_col};
 }
@@ -311,7 +336,7 @@ Tensor dropout_mask(int64_t nnz, int64_t h, uint64_t seed, uint64_t offset, cons
 // materialises the same mask with dropout_mask and takes gat_forward).
 py::object gat_forward_seeded(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
                               const Tensor &col_ind, double negative_slope, const Tensor &in_feat, double attn_drop,
-                              uint64_t seed, uint64_t offset, const OutList &outs) {
+                              uint64_t seed, uint64_t offset, const OutList &outs, bool neg) {
   const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
   c10::DeviceGuard guard(in_feat.device());
   Tensor out = out_f32(outs, 0, {d.m, d.h, d.f}, in_feat, "out_feat");
@@ -319,12 +344,25 @@ py::object gat_forward_seeded(const Tensor &attn_row, const Tensor &attn_col, co
   Tensor edge_sum = out_f32(outs, 2, {d.m, d.h}, in_feat, "edge_sum");
   const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
   Tensor ws = workspace(nb, in_feat);
-  const int rc = API(dgnn_gat_forward_seeded)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
-                                              fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), seed,
-                                              offset, fo(edge_max), fo(edge_sum), fo(out), ptr<void>(ws), nb,
-                                              stream_of(in_feat));
+  Tensor out_neg, a_neg;
+  if (neg && d.m > 0 && d.f % 4 == 0) {
+    out_neg = new_f32({d.m, d.h, d.f}, in_feat);
+    a_neg = new_f32({d.m, d.h}, in_feat);
+  }
+  int rc = API(dgnn_gat_forward_seeded)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
+                                        fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), seed,
+                                        offset, fo(edge_max), fo(edge_sum), fo(out), fo(out_neg), fo(a_neg),
+                                        ptr<void>(ws), nb, stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED && out_neg.defined()) {     // no negative-score pair here: plain seeded forward
+    out_neg = Tensor();
+    a_neg = Tensor();
+    rc = API(dgnn_gat_forward_seeded)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope, fp(attn_row),
+                                      fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), seed, offset, fo(edge_max),
+                                      fo(edge_sum), fo(out), nullptr, nullptr, ptr<void>(ws), nb, stream_of(in_feat));
+  }
   if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
   check_rc(rc, "dgnn_gat_forward_seeded");
+  if (neg) return py::cast(std::vector<Tensor>{out, edge_max, edge_sum, out_neg, a_neg});
   return py::cast(std::vector<Tensor>{out, edge_max, edge_sum});
 }
 
@@ -335,11 +373,12 @@ py::object gat_backward_seeded(double negative_slope, double attn_drop, const Te
                                const Tensor &edge_max, const Tensor &edge_sum, uint64_t seed, uint64_t offset,
                                const Tensor &in_feat, const Tensor &attn_row, const Tensor &attn_col,
                                const Tensor &grad, const OptTensor &out_feat, const OptTensor &row_dot,
-                               const OutList &outs) {
+                               const OutList &outs, const OptTensor &out_neg, const OptTensor &a_neg) {
   i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
   i32(permute, "permute");
   f32(edge_max, "edge_max", 2), f32(edge_sum, "edge_sum", 2), f32(in_feat, "in_feat", 3);
   f32(attn_row, "attn_row", 2), f32(attn_col, "attn_col", 2), f32(grad, "grad", 3);
+  check_neg_pair(out_neg, a_neg, grad);
   const int m = as_int(row_ptr.size(0) - 1, "rows"), nnz = as_int(col_ind.size(0), "nnz");
   const int n = as_int(col_ptr.size(0) - 1, "columns");
   const int h = as_int(in_feat.size(1), "heads"), f = as_int(in_feat.size(2), "features");
@@ -361,8 +400,8 @@ py::object gat_backward_seeded(double negative_slope, double attn_drop, const Te
   const int rc = API(dgnn_gat_backward_seeded)(
       m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind), ip(col_ptr), ip(row_ind),
       ip(permute), fp(edge_max), fp(edge_sum), seed, offset, fp(in_feat), fp(attn_row), fp(attn_col), fp(grad),
-      fp(out_feat), fp(row_dot), fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb,
-      stream_of(in_feat));
+      fp(out_feat), fp(row_dot), fp(out_neg), fp(a_neg), fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col),
+      ptr<void>(ws), nb, stream_of(in_feat));
   if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
   check_rc(rc, "dgnn_gat_backward_seeded");
   return py::cast(std::vector<Tensor>{grad_feat, grad_attn_row, grad_attn_col});
@@ -380,7 +419,7 @@ const uint64_t *rng_state_ptr(const Tensor &rng_state, const Tensor &like) {
 
 py::object gat_forward_seeded_dev(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
                                   const Tensor &col_ind, double negative_slope, const Tensor &in_feat, double attn_drop,
-                                  const Tensor &rng_state, const OutList &outs) {
+                                  const Tensor &rng_state, const OutList &outs, bool neg) {
   const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
   const uint64_t *state = rng_state_ptr(rng_state, in_feat);
   c10::DeviceGuard guard(in_feat.device());
@@ -389,12 +428,26 @@ py::object gat_forward_seeded_dev(const Tensor &attn_row, const Tensor &attn_col
   Tensor edge_sum = out_f32(outs, 2, {d.m, d.h}, in_feat, "edge_sum");
   const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
   Tensor ws = workspace(nb, in_feat);
-  const int rc = API(dgnn_gat_forward_seeded_dev)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
-                                                  fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat),
-                                                  state, fo(edge_max), fo(edge_sum), fo(out), ptr<void>(ws), nb,
-                                                  stream_of(in_feat));
+  Tensor out_neg, a_neg;
+  if (neg && d.m > 0 && d.f % 4 == 0) {
+    out_neg = new_f32({d.m, d.h, d.f}, in_feat);
+    a_neg = new_f32({d.m, d.h}, in_feat);
+  }
+  int rc = API(dgnn_gat_forward_seeded_dev)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
+                                            fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), state,
+                                            fo(edge_max), fo(edge_sum), fo(out), fo(out_neg), fo(a_neg), ptr<void>(ws),
+                                            nb, stream_of(in_feat));
+  if (rc == DGNN_ERR_UNSUPPORTED && out_neg.defined()) {
+    out_neg = Tensor();
+    a_neg = Tensor();
+    rc = API(dgnn_gat_forward_seeded_dev)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope, fp(attn_row),
+                                          fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), state, fo(edge_max),
+                                          fo(edge_sum), fo(out), nullptr, nullptr, ptr<void>(ws), nb,
+                                          stream_of(in_feat));
+  }
   if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
   check_rc(rc, "dgnn_gat_forward_seeded_dev");
+  if (neg) return py::cast(std::vector<Tensor>{out, edge_max, edge_sum, out_neg, a_neg});
   return py::cast(std::vector<Tensor>{out, edge_max, edge_sum});
 }
 
@@ -403,7 +456,9 @@ py::object gat_backward_seeded_dev(double negative_slope, double attn_drop, cons
                                    const Tensor &permute, const Tensor &edge_max, const Tensor &edge_sum,
                                    const Tensor &rng_state, const Tensor &in_feat, const Tensor &attn_row,
                                    const Tensor &attn_col, const Tensor &grad, const OptTensor &out_feat,
-                                   const OptTensor &row_dot, const OutList &outs) {
+                                   const OptTensor &row_dot, const OutList &outs, const OptTensor &out_neg,
+                                   const OptTensor &a_neg) {
+  check_neg_pair(out_neg, a_neg, grad);
   i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
   i32(permute, "permute");
   f32(edge_max, "edge_max", 2), f32(edge_sum, "edge_sum", 2), f32(in_feat, "in_feat", 3);
@@ -430,8 +485,8 @@ py::object gat_backward_seeded_dev(double negative_slope, double attn_drop, cons
   const int rc = API(dgnn_gat_backward_seeded_dev)(
       m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr), ip(col_ind), ip(col_ptr), ip(row_ind),
       ip(permute), fp(edge_max), fp(edge_sum), state, fp(in_feat), fp(attn_row), fp(attn_col), fp(grad),
-      fp(out_feat), fp(row_dot), fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb,
-      stream_of(in_feat));
+      fp(out_feat), fp(row_dot), fp(out_neg), fp(a_neg), fo(grad_feat), fo(grad_attn_row), fo(grad_attn_col),
+      ptr<void>(ws), nb, stream_of(in_feat));
   if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
   check_rc(rc, "dgnn_gat_backward_seeded_dev");
   return py::cast(std::vector<Tensor>{grad_feat, grad_attn_row, grad_attn_col});
@@ -876,7 +931,7 @@ PYBIND11_MODULE(fused_gatconv, m) {
       "generator only when attn_drop > 0 (empty tensor otherwise); edge_mask may be passed explicitly (tests).\n"
       "out = (out_feat, edge_max, edge_sum), entries may be None: write into these tensors instead of new ones.",
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
-      arg("attn_drop"), arg("edge_mask") = py::none(), arg("out") = py::none());
+      arg("attn_drop"), arg("edge_mask") = py::none(), arg("out") = py::none(), arg("neg") = false);
   def(m, "gat_forward_tb", &gat_forward_tb,
       "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, tile_scheduler, tile=32",
       "-> [out_feat, edge_max, edge_sum]   (fused_gatconv.cpp:68-95).  tile_scheduler must be the list the\n"
@@ -902,7 +957,7 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("edge_max"), arg("edge_sum"), arg("edge_mask"), arg("in_feat"), arg("attn_row"),
       arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
-      arg("out") = py::none());
+      arg("out") = py::none(), arg("out_neg") = py::none(), arg("a_neg") = py::none());
   def(m, "dropout_mask", &dropout_mask, "nnz, h, seed, offset, like",
       "-> the [nnz,h] mask (on like's device) the *_seeded functions regenerate from (seed, offset)", arg("nnz"),
       arg("h"), arg("seed"), arg("offset"), arg("like"));
@@ -911,13 +966,13 @@ PYBIND11_MODULE(fused_gatconv, m) {
       "gat_forward with the dropout mask regenerated from (seed, offset): nothing is stored for the backward.\n"
       "-> [out_feat, edge_max, edge_sum], or None where the seeded kernels do not apply.",
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
-      arg("attn_drop"), arg("seed"), arg("offset") = 0, arg("out") = py::none());
+      arg("attn_drop"), arg("seed"), arg("offset") = 0, arg("out") = py::none(), arg("neg") = false);
   def(m, "gat_forward_seeded_dev", &gat_forward_seeded_dev,
       "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, rng_state, out=None",
       "gat_forward_seeded with {seed, offset} read from the int64 device tensor rng_state [2] at launch\n"
       "(capturable into a HIP graph: every replay draws from what the tensor then holds).",
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
-      arg("attn_drop"), arg("rng_state"), arg("out") = py::none());
+      arg("attn_drop"), arg("rng_state"), arg("out") = py::none(), arg("neg") = false);
   def(m, "gat_backward_seeded_dev", &gat_backward_seeded_dev,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, rng_state, "
       "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",
@@ -925,7 +980,7 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("edge_max"), arg("edge_sum"), arg("rng_state"), arg("in_feat"), arg("attn_row"),
       arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
-      arg("out") = py::none());
+      arg("out") = py::none(), arg("out_neg") = py::none(), arg("a_neg") = py::none());
   def(m, "gat_backward_seeded", &gat_backward_seeded,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, seed, offset, "
       "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",
@@ -933,7 +988,7 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("edge_max"), arg("edge_sum"), arg("seed"), arg("offset"), arg("in_feat"), arg("attn_row"),
       arg("attn_col"), arg("grad"), arg("out_feat") = py::none(), arg("row_dot") = py::none(),
-      arg("out") = py::none());
+      arg("out") = py::none(), arg("out_neg") = py::none(), arg("a_neg") = py::none());
   def(m, "gat_backward_packed", &gat_backward_packed,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat, edge_mask, in_feat, "
       "attn_col, grad, out=None",

@@ -25,16 +25,19 @@ def init_capture_rng(device, seed=None):
 
 
 def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):
-    """-> (out_feat, edge_max, edge_sum, edge_mask or None, seed or None).  With attn_drop > 0 the
+    """-> (out_feat, edge_max, edge_sum, edge_mask or None, seed or None, out_neg, a_neg).  The
+    last two (None where the kernels have no such pair) are the aggregate and the softmax-weight sum
+    over the negative-score edges: the backward turns them into grad_attn_row per row instead of
+    scattering [nnz,h] edge gradients and summing them (include/dgnn_hip.h).  With attn_drop > 0 the
     mask is not drawn and kept ([nnz,h] floats: 1 GB per layer at the products shape, what the
     reference saves, fused_gatconv.py:18) but regenerated in the backward from a 62-bit seed taken
     from torch's CPU generator (reproducible under torch.manual_seed, no device sync); shapes the
     seeded kernels do not take get the SAME mask materialised.  Under HIP-graph capture the seed
     is a device tensor instead (see _CAPTURE_RNG)."""
     if not attn_drop > 0:
-        out, emax, esum, mask = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope,
-                                                      in_feat, attn_drop)
-        return out, emax, esum, mask, None
+        out, emax, esum, mask, on, an = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope,
+                                                              in_feat, attn_drop, neg=True)
+        return out, emax, esum, mask, None, on, an
     if torch.cuda.is_current_stream_capturing():
         from .._lib import DgnnError
         state = _CAPTURE_RNG.get(in_feat.device)
@@ -45,41 +48,42 @@ def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, 
         mine = state.clone()                      # captured copy: what THIS forward and its backward read
         state[1:].add_(1)                         # captured: the next forward / the next replay draws another mask
         res = fused_gat.gat_forward_seeded_dev(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat,
-                                               attn_drop, mine)
+                                               attn_drop, mine, neg=True)
         if res is None:
             raise DgnnError("attn_drop > 0 under HIP-graph capture: this shape is outside the seeded kernels "
                             "(heads > 8 or misaligned rows); capture without dropout or run it eagerly")
-        return res[0], res[1], res[2], None, mine
+        return res[0], res[1], res[2], None, mine, res[3], res[4]
     seed = int(torch.randint(0, 1 << 62, (1,)).item())
     if in_feat.device not in _CAPTURE_RNG:
         # derived from this call's seed: no extra draw from torch's generator (the sequence of
         # eager seeds under torch.manual_seed stays what it was)
         init_capture_rng(in_feat.device, seed=seed ^ 0x2545F4914F6CDD1D)
-    res = fused_gat.gat_forward_seeded(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, seed)
+    res = fused_gat.gat_forward_seeded(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, seed,
+                                       neg=True)
     if res is not None:
-        return res[0], res[1], res[2], None, seed
+        return res[0], res[1], res[2], None, seed, res[3], res[4]
     mask = fused_gat.dropout_mask(col_ind.size(0), attn_row.size(1), seed, 0, in_feat)
     out, emax, esum, mask = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat,
                                                   attn_drop, edge_mask=mask)
-    return out, emax, esum, mask, None
+    return out, emax, esum, mask, None, None, None
 
 
 def _backward_with_dropout(ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask,
-                           in_feat, attn_row, attn_col, grad_out, out_feat):
+                           in_feat, attn_row, attn_col, grad_out, out_feat, out_neg=None, a_neg=None):
     if isinstance(ctx.seed, torch.Tensor):        # forward ran under capture: device pair
         return fused_gat.gat_backward_seeded_dev(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr,
                                                  row_ind, permute, edge_max, edge_sum, ctx.seed, in_feat, attn_row,
-                                                 attn_col, grad_out, out_feat=out_feat)
+                                                 attn_col, grad_out, out_feat=out_feat, out_neg=out_neg, a_neg=a_neg)
     if ctx.seed is not None:
         res = fused_gat.gat_backward_seeded(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind,
                                             permute, edge_max, edge_sum, ctx.seed, 0, in_feat, attn_row, attn_col,
-                                            grad_out, out_feat=out_feat)
+                                            grad_out, out_feat=out_feat, out_neg=out_neg, a_neg=a_neg)
         if res is not None:
             return res
         edge_mask = fused_gat.dropout_mask(col_ind.size(0), attn_row.size(1), ctx.seed, 0, in_feat)
     return fused_gat.gat_backward(ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
                                   edge_max, edge_sum, edge_mask, in_feat, attn_row, attn_col, grad_out,
-                                  out_feat=out_feat)
+                                  out_feat=out_feat, out_neg=out_neg, a_neg=a_neg)
 
 
 def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope,
@@ -109,10 +113,10 @@ class FusedGATFunction(torch.autograd.Function):
         attn_col = attn_col.contiguous()
         ctx.f = in_feat.size(2)
         in_feat = _pad4(in_feat.contiguous())          # odd widths run padded (see _pad4)
-        out_feat, edge_max, edge_sum, edge_mask, ctx.seed = _forward_with_dropout(
+        out_feat, edge_max, edge_sum, edge_mask, ctx.seed, out_neg, a_neg = _forward_with_dropout(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
-                              edge_mask, in_feat, attn_row, attn_col, out_feat)
+                              edge_mask, in_feat, attn_row, attn_col, out_feat, out_neg, a_neg)
         ctx.negative_slope = negative_slope
         ctx.attn_drop = attn_drop
         return out_feat if out_feat.size(2) == ctx.f else out_feat[..., :ctx.f]
@@ -120,11 +124,11 @@ class FusedGATFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
-         attn_row, attn_col, out_feat) = ctx.saved_tensors
+         attn_row, attn_col, out_feat, out_neg, a_neg) = ctx.saved_tensors
         grad_out = _pad_to(grad_out, in_feat.size(2)).contiguous()   # fused_gatconv.py:26; the forward's width
         grad_feat, grad_attn_row, grad_attn_col = _backward_with_dropout(
             ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
-            attn_row, attn_col, grad_out, out_feat)
+            attn_row, attn_col, grad_out, out_feat, out_neg, a_neg)
         if grad_feat.size(2) != ctx.f:
             grad_feat = grad_feat[..., :ctx.f]
         # same tuple layout as fused_gatconv.py:34
@@ -158,11 +162,11 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
         attn_row, attn_col = scores
         ctx.f = feat.size(2)
         feat_p = _pad4(feat)                              # odd widths run padded (see _pad4)
-        out_feat, edge_max, edge_sum, edge_mask, ctx.seed = _forward_with_dropout(
+        out_feat, edge_max, edge_sum, edge_mask, ctx.seed, out_neg, a_neg = _forward_with_dropout(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, feat_p, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
                               edge_mask, feat, attn_row, attn_col, out_feat, attn_l, attn_r,
-                              feat_p if feat_p is not feat else None)
+                              feat_p if feat_p is not feat else None, out_neg, a_neg)
         ctx.negative_slope = negative_slope
         ctx.attn_drop = attn_drop
         return out_feat if out_feat.size(2) == ctx.f else out_feat[..., :ctx.f]
@@ -170,11 +174,11 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, feat,
-         attn_row, attn_col, out_feat, attn_l, attn_r, feat_p) = ctx.saved_tensors
+         attn_row, attn_col, out_feat, attn_l, attn_r, feat_p, out_neg, a_neg) = ctx.saved_tensors
         grad_feat, g_row, g_col = _backward_with_dropout(
             ctx, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask,
             feat if feat_p is None else feat_p, attn_row, attn_col,
-            _pad_to(grad_out, out_feat.size(2)).contiguous(), out_feat)
+            _pad_to(grad_out, out_feat.size(2)).contiguous(), out_feat, out_neg, a_neg)
         if grad_feat.size(2) != ctx.f:
             grad_feat = grad_feat[..., :ctx.f].contiguous()
         if ctx.fused_scores:

@@ -68,11 +68,19 @@ size_t dgnn_gat_forward_workspace_bytes(int m, int nnz, int h, int f);
  *             scaled by 1/(1-attn_drop) (:104).  May be NULL iff attn_drop == 0 (the
  *             reference always draws a mask with cuRAND, :333-341; with attn_drop == 0 it
  *             keeps every edge, so no mask is needed and none is read).
- * Empty row: edge_max = -1e38f, edge_sum = 0, out_feat = 0 (:45,:66,:90). */
+ * Empty row: edge_max = -1e38f, edge_sum = 0, out_feat = 0 (:45,:66,:90).
+ *   out_neg [m,h,f], a_neg [m,h]  OPTIONAL pair (both or neither; no counterpart in the reference):
+ *             the same aggregate and the sum of the (unmasked) softmax weights restricted to the
+ *             edges whose LeakyReLU score is negative.  Handed to dgnn_gat_backward they replace
+ *             its [nnz,h] edge-gradient scatter and per-row sums: with sl_j = (e_j < 0 ? slope : 1),
+ *               grad_attn_row = sum_j a_j (g_j - S) sl_j = (1 - slope) (S * a_neg - <grad, out_neg>)
+ *             (fused_backward_kernel :952-967 restated per row).  float4 rows (f % 4 == 0, 16-byte
+ *             aligned) on the neighbour-grouped kernels; otherwise DGNN_ERR_UNSUPPORTED: call again
+ *             with NULLs. */
 int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
                      const float *attn_row, const float *attn_col, const int *row_ptr,
                      const int *col_ind, const float *in_feat, const float *edge_mask,
-                     float *edge_max, float *edge_sum, float *out_feat,
+                     float *edge_max, float *edge_sum, float *out_feat, float *out_neg, float *a_neg,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* dgnn_gat_forward WITHOUT a workspace argument and without any allocation.  No counterpart in
@@ -145,6 +153,11 @@ size_t dgnn_gat_backward_workspace_bytes(int m, int n, int nnz, int h, int f, in
  *   row_dot [m,h]     OPTIONAL precomputed S (dgnn_gat_row_dot); takes precedence over out_feat.
  *                     Both NULL = rebuild out_feat with one extra forward pass (the reference
  *                     signature carries neither).
+ *   out_neg [m,h,f], a_neg [m,h]  OPTIONAL pair saved by the forward (see dgnn_gat_forward): with
+ *                     it grad_attn_row comes out of the per-row pass and the column pass writes no
+ *                     edge gradients (no [nnz,h] scatter through permute, no per-row sums).  Used
+ *                     on the float4 neighbour-grouped kernels, silently ignored elsewhere (the
+ *                     edge-gradient path computes the same values).
  *   grad_feat [n,h,f], grad_attn_row [m,h], grad_attn_col [n,h]: outputs, fully written
  *   (no pre-zeroing by the caller; the reference zeroes grad_attn_col itself, :1057). */
 int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
@@ -152,9 +165,9 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
                       const int *row_ind, const int *permute, const float *edge_max,
                       const float *edge_sum, const float *edge_mask, const float *in_feat,
                       const float *attn_row, const float *attn_col, const float *grad,
-                      const float *out_feat, const float *row_dot, float *grad_feat,
-                      float *grad_attn_row, float *grad_attn_col, void *workspace,
-                      size_t workspace_bytes, void *stream);
+                      const float *out_feat, const float *row_dot, const float *out_neg,
+                      const float *a_neg, float *grad_feat, float *grad_attn_row,
+                      float *grad_attn_col, void *workspace, size_t workspace_bytes, void *stream);
 
 /* dgnn_gat_backward with the per-row inputs handed over PACKED: row_stat [m,h,4] =
  * {attn_row, edge_max, edge_sum, row_dot} per (row, head), the 16-byte records the column-gather
@@ -189,16 +202,17 @@ int dgnn_gat_forward_seeded(int m, int nnz, int h, int f, float attn_drop, float
                             const float *attn_row, const float *attn_col, const int *row_ptr,
                             const int *col_ind, const float *in_feat, uint64_t seed,
                             uint64_t offset, float *edge_max, float *edge_sum, float *out_feat,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            float *out_neg, float *a_neg, void *workspace, size_t workspace_bytes,
+                            void *stream);
 int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative_slope,
                              float attn_drop, const int *row_ptr, const int *col_ind,
                              const int *col_ptr, const int *row_ind, const int *permute,
                              const float *edge_max, const float *edge_sum, uint64_t seed,
                              uint64_t offset, const float *in_feat, const float *attn_row,
                              const float *attn_col, const float *grad, const float *out_feat,
-                             const float *row_dot, float *grad_feat, float *grad_attn_row,
-                             float *grad_attn_col, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             const float *row_dot, const float *out_neg, const float *a_neg,
+                             float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* The seeded entry points with (seed, offset) read FROM DEVICE MEMORY at launch: rng_state points
  * to two uint64 {seed, offset} (8-byte aligned).  A launch captured into a HIP graph bakes its
@@ -210,14 +224,15 @@ int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative
 int dgnn_gat_forward_seeded_dev(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
                                 const float *attn_row, const float *attn_col, const int *row_ptr,
                                 const int *col_ind, const float *in_feat, const uint64_t *rng_state,
-                                float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                                size_t workspace_bytes, void *stream);
+                                float *edge_max, float *edge_sum, float *out_feat, float *out_neg,
+                                float *a_neg, void *workspace, size_t workspace_bytes, void *stream);
 int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float negative_slope,
                                  float attn_drop, const int *row_ptr, const int *col_ind,
                                  const int *col_ptr, const int *row_ind, const int *permute,
                                  const float *edge_max, const float *edge_sum, const uint64_t *rng_state,
                                  const float *in_feat, const float *attn_row, const float *attn_col,
                                  const float *grad, const float *out_feat, const float *row_dot,
+                                 const float *out_neg, const float *a_neg,
                                  float *grad_feat, float *grad_attn_row, float *grad_attn_col,
                                  void *workspace, size_t workspace_bytes, void *stream);
 

@@ -119,6 +119,75 @@ def test_gat_every_group_size(nat, name, fwd_l, bwd_l, h, f, monkeypatch):
     assert_close(host(gc), gc64, "grad_attn_col", mass=m_gc)
 
 
+@pytest.mark.parametrize("name", ["deg_edges", "powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 64), (4, 16), (8, 8), (2, 100), (8, 64), (4, 128), (3, 20)])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("fwd_l", [0, 64])
+def test_gat_negative_score_pair_replaces_the_edge_gradient_round_trip(nat, name, h, f, p, fwd_l, monkeypatch):
+    """gat_forward(neg=True) also returns out_neg [m,h,f] / a_neg [m,h], the aggregate and the
+    (unmasked) softmax-weight sum over the edges with a negative LeakyReLU score; given to
+    gat_backward they yield grad_attn_row = (1 - slope)(S a_neg - <grad, out_neg>) in the row pass,
+    with no [nnz,h] edge-gradient scatter.  Both against float64: the pair itself, and every
+    gradient of the backward that uses it (which must also agree with the edge-gradient path)."""
+    if fwd_l:
+        monkeypatch.setenv("DGNN_FWD_L", str(fwd_l))
+        monkeypatch.setenv("DGNN_BWD_L", "64")
+    g = GRAPHS[name]
+    slope = 0.2
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=31)
+    mask = np.random.default_rng(6).random((g["nnz"], h), dtype=np.float32) if p > 0 else None
+    G = gdev(g)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    dm = dev(mask) if mask is not None else None
+    out, emax, esum, emask, out_neg, a_neg = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], slope, x, p,
+                                                                    edge_mask=dm, neg=True)
+    assert out_neg is not None and out_neg.shape == out.shape and a_neg.shape == (g["n"], h)
+    # float64 reference of the pair
+    row = np.repeat(np.arange(g["n"]), np.diff(g["row_ptr"]))
+    col = g["col_ind"].astype(np.int64)
+    e = attn_row.astype(np.float64)[row] + attn_col.astype(np.float64)[col]
+    e = np.where(e > 0, e, e * slope)
+    mx = np.full((g["n"], h), -np.inf)
+    np.maximum.at(mx, row, e)
+    ex = np.exp(e - mx[row])
+    sm = np.zeros((g["n"], h))
+    np.add.at(sm, row, ex)
+    a = ex / sm[row]
+    negm = (e < 0)
+    want_an = np.zeros((g["n"], h))
+    np.add.at(want_an, row, np.where(negm, a, 0.0))
+    w = a if mask is None else np.where(mask > np.float32(p), a / (1.0 - p), 0.0)
+    want_on = np.zeros((g["n"], h, f))
+    np.add.at(want_on, row, (np.where(negm, w, 0.0))[:, :, None] * in_feat.astype(np.float64)[col])
+    m_out = gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p)[0]
+    assert_close(host(a_neg), want_an, "a_neg")
+    assert_close(host(out_neg), want_on, "out_neg", mass=m_out)
+    # scores that are exactly the boundary e == 0 do not occur with these inputs; the kernel's
+    # test is e < 0 like the reference's `val_leaky < 0` (fused_gatconv_kernel.cu:953)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(slope, p, g["row_ptr"], g["col_ind"], mask, in_feat, attn_row, attn_col, grad)
+    _, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p)
+    with_pair = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                        emax, esum, emask, x, ar, ac, go, out_feat=out, out_neg=out_neg, a_neg=a_neg)
+    plain = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                    emax, esum, emask, x, ar, ac, go, out_feat=out)
+    assert_close(host(with_pair[0]), gf64, "neg pair: grad_feat", mass=m_gf)
+    assert_close(host(with_pair[1]), gr64, "neg pair: grad_attn_row", mass=m_gr)
+    assert_close(host(with_pair[2]), gc64, "neg pair: grad_attn_col", mass=m_gc)
+    assert torch.equal(with_pair[0], plain[0]) and torch.equal(with_pair[2], plain[2]), "the column pass is unchanged"
+    assert_close(host(plain[1]), gr64, "edge-gradient path: grad_attn_row", mass=m_gr)
+
+
+def test_gat_negative_score_pair_shapes_without_it(nat):
+    """Rows that are not float4 (f % 4 != 0) and more than eight heads have no pair: neg=True
+    returns None for both and the backward works as before."""
+    g = GRAPHS["powerlaw256"]
+    for h, f in ((1, 47), (9, 8)):
+        in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=2)
+        G = gdev(g)
+        res = nat["gat"].gat_forward(dev(attn_row), dev(attn_col), G["row_ptr"], G["col_ind"], 0.2, dev(in_feat), 0.0, neg=True)
+        assert len(res) == 6 and res[4] is None and res[5] is None
+
+
 def test_gat_caller_provided_outputs(nat):
     """out=(...) of gat_forward / gat_backward (row slices of larger tensors, as the chunked
     multi-GPU runner passes them): same bits as the allocating call, written in place; wrong

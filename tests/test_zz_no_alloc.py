@@ -44,7 +44,7 @@ def _forward_both(g, h, f, seed, p=0.0, check_oracle=True):
     mx0, sm0, out0 = outputs()
     _lib.check(lib.dgnn_gat_forward(n, nnz, h, f, p, SLOPE, _lib.p(d["ar"]), _lib.p(d["ac"]), _lib.p(d["rp"]),
                                     _lib.p(d["ci"]), _lib.p(d["x"]), _lib.p(d["mk"]), _lib.p(mx0), _lib.p(sm0),
-                                    _lib.p(out0), _lib.p(ws), need, st), "dgnn_gat_forward")
+                                    _lib.p(out0), None, None, _lib.p(ws), need, st), "dgnn_gat_forward")
     # new entry point: no workspace, no allocation
     mx1, sm1, out1 = outputs()
     torch.cuda.synchronize()
