@@ -107,13 +107,19 @@ def build_graph(name, device, seed=0, labels="natural"):
     return graph_from_keys(keys, n, device)
 
 
-def algorithmic_bytes(n, nnz, h, f):
-    """SURVEY.md section 8(d) gather model (attn_drop = 0).  Returns per-phase byte counts."""
+def algorithmic_bytes(n, nnz, h, f, neg=True):
+    """SURVEY.md section 8(d) gather model (attn_drop = 0).  Returns per-phase byte counts.
+    neg: the training path of round 2 -- the forward also writes the negative-score pair (out_neg
+    [n,h,f], a_neg [n,h]) and the backward's gather pass neither reads permute nor writes the
+    [nnz,h] edge gradients (grad_attn_row comes out of the per-row pass)."""
     hf = h * f
     fwd = nnz * (4 * hf + 4 * h + 4) + n * (4 * hf + 16 * h + 4)          # gather + out + stats
-    # backward, one gather pass: grad rows + packed row stats + row_ind/permute + dE write,
+    # backward, one gather pass: grad rows + packed row stats + row_ind (+ permute + dE write),
     # per node in_feat row + grad_feat write + pointers/scalars
     bwd_csc = nnz * (4 * hf + 16 * h + 8 + 4 * h) + n * (8 * hf + 8 * h + 4)
+    if neg:
+        fwd += n * (4 * hf + 4 * h)
+        bwd_csc -= nnz * (4 + 4 * h)
     total_model = nnz * (12 * hf + 28 * h + 12) + n * (12 * hf + 36 * h + 8)  # BASELINE.md formula
     return dict(fwd=fwd, bwd_csc=bwd_csc, survey_total=total_model)
 
@@ -354,11 +360,12 @@ def main():
         xd, ard, acd = in_feat.detach(), attn_row.detach(), attn_col.detach()
         for _ in range(reps):
             ev[0].record()
-            out, emax, esum, emask = fused_gatconv.gat_forward(ard, acd, g["row_ptr"], g["col_ind"], SLOPE, xd,
-                                                               args.attn_drop)
+            out, emax, esum, emask, out_neg, a_neg = fused_gatconv.gat_forward(
+                ard, acd, g["row_ptr"], g["col_ind"], SLOPE, xd, args.attn_drop, neg=True)     # as the operator calls it
             ev[1].record()
             fused_gatconv.gat_backward(SLOPE, args.attn_drop, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
-                                       g["permute"], emax, esum, emask, xd, ard, acd, grad_out, out_feat=out)
+                                       g["permute"], emax, esum, emask, xd, ard, acd, grad_out, out_feat=out,
+                                       out_neg=out_neg, a_neg=a_neg)
             ev[2].record()
             torch.cuda.synchronize()
             tf += ev[0].elapsed_time(ev[1])

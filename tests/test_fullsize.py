@@ -49,12 +49,16 @@ def big(request):
     ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
     ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
     grad = torch.rand((n, H, F), device=dev, generator=gen) - 0.5
-    out, emax, esum, emask = fused_gatconv.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], SLOPE, x, 0.0)
+    # the operator's own path: forward with the negative-score pair, backward fed with it
+    out, emax, esum, emask, out_neg, a_neg = fused_gatconv.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], SLOPE, x, 0.0,
+                                                                       neg=True)
+    assert out_neg is not None
     gf, gr, gc = fused_gatconv.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
-                                            g["permute"], emax, esum, emask, x, ar, ac, grad, out_feat=out)
+                                            g["permute"], emax, esum, emask, x, ar, ac, grad, out_feat=out,
+                                            out_neg=out_neg, a_neg=a_neg)
     torch.cuda.synchronize()
     return dict(g=g, x=x, ar=ar, ac=ac, grad=grad, out=out, emax=emax, esum=esum, emask=emask,
-                gf=gf, gr=gr, gc=gc, ops=fused_gatconv)
+                gf=gf, gr=gr, gc=gc, ops=fused_gatconv, out_neg=out_neg, a_neg=a_neg)
 
 
 def test_graph_is_the_headline_shape(big):
@@ -115,9 +119,17 @@ def test_scaling_by_two_is_bit_exact(big):
     # the backward is linear in grad for fixed inputs; S = <grad, out> scales with it
     gf2, gr2, gc2 = ops.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
                                      g["permute"], big["emax"], big["esum"], big["emask"], big["x"],
-                                     big["ar"], big["ac"], big["grad"] * 2.0, out_feat=big["out"])
+                                     big["ar"], big["ac"], big["grad"] * 2.0, out_feat=big["out"],
+                                     out_neg=big["out_neg"], a_neg=big["a_neg"])
     assert torch.equal(gf2, big["gf"] * 2.0)
     assert torch.equal(gr2, big["gr"] * 2.0) and torch.equal(gc2, big["gc"] * 2.0)
+    # the edge-gradient path (reference-shaped call, no pair) gives the same grad_attn_row within the band
+    gf3, gr3, gc3 = ops.gat_backward(SLOPE, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                                     g["permute"], big["emax"], big["esum"], big["emask"], big["x"],
+                                     big["ar"], big["ac"], big["grad"], out_feat=big["out"])
+    assert torch.equal(gf3, big["gf"]) and torch.equal(gc3, big["gc"])
+    scale = big["gr"].abs().max().item()
+    assert (gr3 - big["gr"]).abs().max().item() <= 1e-4 * scale
 
 
 def test_attention_gradients_sum_to_the_same_total(big):

@@ -108,11 +108,15 @@ def shapes(workload="products"):
         ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
         ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
         go = torch.rand((n, H, F), device=dev, generator=gen) - 0.5
-        out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
-        tf = timeit(lambda: fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0), iters=3, warm=1)
+        neg = os.environ.get("DGNN_BENCH_NEG", "1") == "1"      # the operator's path: negative-score pair
+        out, emax, esum, emask, on, an = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=True)
+        if not neg:
+            on = an = None
+        tf = timeit(lambda: fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=neg), iters=3, warm=1)
         tb = timeit(lambda: fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"],
-                                            emax, esum, emask, x, ar, ac, go, out_feat=out), iters=3, warm=1)
-        ab = bench.algorithmic_bytes(n, nnz, H, F)
+                                            emax, esum, emask, x, ar, ac, go, out_feat=out, out_neg=on, a_neg=an),
+                    iters=3, warm=1)
+        ab = bench.algorithmic_bytes(n, nnz, H, F, neg=neg and on is not None)
         print(json.dumps({"op": f"gat {workload}", "H": H, "F": F, "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
                           "fwd_GBps": round(ab["fwd"] / tf / 1e6, 1), "bwd_GBps": round(ab["bwd_csc"] / tb / 1e6, 1)}), flush=True)
         del x, go, out
