@@ -499,7 +499,11 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
   if (n < 0) return DGNN_ERR_BAD_ARG;
   if (!row_ptr || !col_ptr) return DGNN_ERR_BAD_ARG;
   if (m > 0 && !packed && (!edge_max || !edge_sum || !attn_row)) return DGNN_ERR_BAD_ARG;
-  if (m > 0 && (!grad || !grad_attn_row)) return DGNN_ERR_BAD_ARG;
+  if (m > 0 && !grad) return DGNN_ERR_BAD_ARG;
+  // grad_attn_row == NULL: the caller computes it itself from the forward's negative-score pair
+  // (the row-partitioned runner: a row's owner holds everything that formula needs); then no
+  // edge gradients are produced at all.  Only the neighbour-grouped kernels can leave them out.
+  const bool no_row_grad = (grad_attn_row == nullptr);
   if (n > 0 && (!in_feat || !attn_col || !grad_feat || !grad_attn_col)) return DGNN_ERR_BAD_ARG;
   if (nnz > 0 && (!col_ind || !row_ind || !permute)) return DGNN_ERR_BAD_ARG;
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
@@ -531,8 +535,10 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
   if (packed != nullptr && !(fast && aligned16(packed))) return DGNN_ERR_UNSUPPORTED;
   // grad_attn_row from the forward's negative-score pair (row pass) instead of the [nnz,h] edge
   // gradients: the fast float4 kernels with the unpacked per-row inputs
-  const bool neg = fast && vec == 4 && out_neg != nullptr && packed == nullptr && m > 0 && aligned16(out_neg);
+  const bool neg = fast && vec == 4 && out_neg != nullptr && packed == nullptr && m > 0 && aligned16(out_neg) &&
+                   !no_row_grad;
   if (rng.on && !fast) return DGNN_ERR_UNSUPPORTED;   // the wave-per-column kernel reads a materialised mask
+  if (no_row_grad && !fast && m > 0) return DGNN_ERR_UNSUPPORTED;
   if (fast) {
     BwdParams P = {};
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
@@ -548,7 +554,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.S_in = row_dot;
     P.out_neg = neg ? out_neg : nullptr; P.a_neg = neg ? a_neg : nullptr; P.grad_attn_row = grad_attn_row;
     P.rowstat = packed ? const_cast<float4 *>(packed) : (float4 *)(ws + w.off_stat);
-    P.dE = neg ? nullptr : dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
+    P.dE = (neg || no_row_grad) ? nullptr : dE; P.grad_feat = grad_feat; P.grad_attn_col = grad_attn_col;
     P.task_col0 = (int *)(ws + w.off_cols);
     P.slots = (float *)(ws + w.off_slots);
     if (m > 0 && !packed) {
@@ -594,7 +600,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
       DGNN_LAUNCH_CHECK();
     }
   }
-  if (m > 0 && !neg) {
+  if (m > 0 && !neg && !no_row_grad) {
     int *long_count = (int *)(ws + w.off_long);
     hipError_t e = hipMemsetAsync(long_count, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;

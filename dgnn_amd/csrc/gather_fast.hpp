@@ -201,13 +201,17 @@ __device__ __forceinline__ void st_heads(float *p, const float (&d)[HT]) {
 
 // One edge into the accumulator(s).  NEG: the staged weight carries the sign bit of its score; the
 // plain aggregate takes |w|, the negative-score aggregate takes |w| only where the bit is set.
+// `an` sums the negative-score weights themselves (a_neg when no dropout is active: then the staged
+// weight IS the softmax weight; under dropout phase B reduces the unmasked weights instead).
 template <bool NEG, int VEC>
-__device__ __forceinline__ void acc_edge(typename VecT<VEC>::type &acc, typename VecT<VEC>::type &accn, float w,
-                                         const typename VecT<VEC>::type &x) {
+__device__ __forceinline__ void acc_edge(typename VecT<VEC>::type &acc, typename VecT<VEC>::type &accn, float &an,
+                                         float w, const typename VecT<VEC>::type &x) {
   if constexpr (NEG) {
     const float wa = fabsf(w);
+    const float wn = (__float_as_uint(w) & 0x80000000u) ? wa : 0.f;
     VecT<VEC>::fma(acc, wa, x);
-    VecT<VEC>::fma(accn, (__float_as_uint(w) & 0x80000000u) ? wa : 0.f, x);
+    VecT<VEC>::fma(accn, wn, x);
+    an += wn;
   } else {
     VecT<VEC>::fma(acc, w, x);
   }
@@ -288,6 +292,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   wave_lds_sync();
 
   // ---------------------------------------------------------------- phase B: rows of the group
+  // a_neg: without dropout the staged weight is the softmax weight itself and phase C sums it
+  // along the way (one add per step); under dropout the staged weight is masked, so the unmasked
+  // sum is reduced here (one more wave reduction per head and row)
+  const bool an_in_b = NEG && (P.edge_mask != nullptr || P.rng.on);
   int nflush = 0;
   {
     int r = uniform_i32(P.task_row0[t]);
@@ -340,10 +348,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           for (int h = 0; h < HTA; ++h) sm[h] = wave_sum(pe[h]);
           float an[HTA];
           if constexpr (NEG) {
+            if (an_in_b) {
 #pragma unroll
-            for (int h = 0; h < HTA; ++h) {
-              an[h] = wave_sum((live && e[h] < 0.f) ? pe[h] : 0.f);
-              if (whole) an[h] = an[h] / sm[h];
+              for (int h = 0; h < HTA; ++h) {
+                an[h] = wave_sum((live && e[h] < 0.f) ? pe[h] : 0.f);
+                if (whole) an[h] = an[h] / sm[h];
+              }
             }
           }
           if (live) {
@@ -377,11 +387,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 st_heads<HTA>(P.edge_max + (size_t)r * HTA, mx);
                 st_heads<HTA>(P.edge_sum + (size_t)r * HTA, sm);
               }
-              if constexpr (NEG) st_heads<HTA>(P.a_neg + (size_t)r * HTA, an);
+              if constexpr (NEG) {
+                if (an_in_b) st_heads<HTA>(P.a_neg + (size_t)r * HTA, an);
+              }
             } else {
               st_heads<HTA>(slot_ptr + P.HF, mx);
               st_heads<HTA>(slot_ptr + P.HF + HTA, sm);
-              if constexpr (NEG) st_heads<HTA>(slot_ptr + P.HF + 2 * HTA, an);
+              if constexpr (NEG) {
+                if (an_in_b) st_heads<HTA>(slot_ptr + P.HF + 2 * HTA, an);
+              }
             }
           }
         } else if (MODE == MODE_GAT && H == 4 && (b - a) <= DGNN_WAVE) {
@@ -413,9 +427,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           sm.x = wave_sum(pe.x); sm.y = wave_sum(pe.y); sm.z = wave_sum(pe.z); sm.w = wave_sum(pe.w);
           float4 an4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if constexpr (NEG) {
-            an4.x = wave_sum(e4.x < 0.f ? pe.x : 0.f); an4.y = wave_sum(e4.y < 0.f ? pe.y : 0.f);
-            an4.z = wave_sum(e4.z < 0.f ? pe.z : 0.f); an4.w = wave_sum(e4.w < 0.f ? pe.w : 0.f);
-            if (whole) { an4.x /= sm.x; an4.y /= sm.y; an4.z /= sm.z; an4.w /= sm.w; }
+            if (an_in_b) {
+              an4.x = wave_sum(e4.x < 0.f ? pe.x : 0.f); an4.y = wave_sum(e4.y < 0.f ? pe.y : 0.f);
+              an4.z = wave_sum(e4.z < 0.f ? pe.z : 0.f); an4.w = wave_sum(e4.w < 0.f ? pe.w : 0.f);
+              if (whole) { an4.x /= sm.x; an4.y /= sm.y; an4.z /= sm.z; an4.w /= sm.w; }
+            }
           }
           if (live) {
             float4 w4 = pe;
@@ -444,11 +460,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                 *(float4 *)(P.edge_max + (size_t)r * 4) = mx;
                 *(float4 *)(P.edge_sum + (size_t)r * 4) = sm;
               }
-              if constexpr (NEG) *(float4 *)(P.a_neg + (size_t)r * 4) = an4;
+              if constexpr (NEG) {
+                if (an_in_b) *(float4 *)(P.a_neg + (size_t)r * 4) = an4;
+              }
             } else {
               *(float4 *)(slot_ptr + P.HF) = mx;
               *(float4 *)(slot_ptr + P.HF + 4) = sm;
-              if constexpr (NEG) *(float4 *)(slot_ptr + P.HF + 8) = an4;
+              if constexpr (NEG) {
+                if (an_in_b) *(float4 *)(slot_ptr + P.HF + 8) = an4;
+              }
             }
           }
         } else if (MODE == MODE_GAT) {
@@ -468,8 +488,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             }
             sm = wave_sum(sm);
             if constexpr (NEG) {
-              an = wave_sum(an);
-              if (whole) an = an / sm;
+              if (an_in_b) {
+                an = wave_sum(an);
+                if (whole) an = an / sm;
+              }
             }
             for (int p = a + lane; p < b; p += DGNN_WAVE) {
               float w = sc[(size_t)p * H + h];
@@ -490,11 +512,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                   P.edge_max[(size_t)r * H + h] = mx;
                   P.edge_sum[(size_t)r * H + h] = sm;
                 }
-                if constexpr (NEG) P.a_neg[(size_t)r * H + h] = an;
+                if constexpr (NEG) {
+                  if (an_in_b) P.a_neg[(size_t)r * H + h] = an;
+                }
               } else {
                 slot_ptr[P.HF + h] = mx;
                 slot_ptr[P.HF + H + h] = sm;
-                if constexpr (NEG) slot_ptr[P.HF + 2 * H + h] = an;
+                if constexpr (NEG) {
+                  if (an_in_b) slot_ptr[P.HF + 2 * H + h] = an;
+                }
               }
             }
           }
@@ -541,6 +567,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       const size_t lane_off = (size_t)(active ? sl : 0) * 4;
       const float *wbase = sc + head;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accn = acc;
+      float an = 0.f;
+      const bool an_leader = active && g == 0 && (sl * 4) % P.F == 0;
       float4 ring[DGNN_FAST_U];
       float wring[DGNN_FAST_U];
       int q = 0;
@@ -554,7 +582,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         x = *(const float4 *)(P.in_feat + (size_t)c * P.HF + lane_off);
       };
       auto consume = [&](const float4 &x, float w, int j) {
-        acc_edge<NEG, 4>(acc, accn, w, x);
+        acc_edge<NEG, 4>(acc, accn, an, w, x);
         if (uniform_i32((int)steps[j]) & (int)DGNN_PACK_END) {
           for (int off = S; off < DGNN_WAVE; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
@@ -566,6 +594,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
               accn.y += __shfl_xor(accn.y, off, DGNN_WAVE);
               accn.z += __shfl_xor(accn.z, off, DGNN_WAVE);
               accn.w += __shfl_xor(accn.w, off, DGNN_WAVE);
+              an += __shfl_xor(an, off, DGNN_WAVE);
             }
           }
           const int d = uniform_i32(dq[q]);
@@ -580,6 +609,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                                    : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
               if (active && g == 0) *(float4 *)(dn + lane_off) = accn;
               accn = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (!an_in_b && an_leader) {
+                if (d >= 0) P.a_neg[(size_t)d * H + head] = an;
+                else P.slots[(size_t)(-(d + 1)) * P.slot_stride + P.HF + 2 * H + head] = an;
+              }
+              an = 0.f;
             }
           }
           acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -636,6 +670,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     size_t lane_off[NS];
     const float *wbase[NS];
     vec_t acc[NS], accn[NS];
+    float an[NS];
+    bool an_leader[NS];
+    int an_head[NS];
     vec_t ring[DGNN_FAST_U][NS];
     float wring[DGNN_FAST_U][NS];
     int hd0 = 0;                           // head of the lane's first slot (summed store)
@@ -648,6 +685,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       wbase[s] = sc + head;
       acc[s] = V::zero();
       accn[s] = V::zero();
+      an[s] = 0.f;
+      an_head[s] = head;
+      an_leader[s] = active[s] && (vslot * VEC) % P.F == 0;
       if (s == 0) hd0 = head;
     }
     int q = 0;
@@ -656,7 +696,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     // One edge of the stream: accumulate (w, x) and flush at a row end.
     auto consume = [&](const vec_t (&x)[NS], const float (&w)[NS], unsigned ci) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc_edge<NEG, VEC>(acc[s], accn[s], w[s], x[s]);
+      for (int s = 0; s < NS; ++s) acc_edge<NEG, VEC>(acc[s], accn[s], an[s], w[s], x[s]);
       if (ci & DGNN_ROWEND) {
         const int d = uniform_i32(dq[q]);
         ++q;
@@ -680,6 +720,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           for (int s = 0; s < NS; ++s) {
             if (active[s]) *(vec_t *)(dn + lane_off[s]) = accn[s];
             accn[s] = V::zero();
+            if (!an_in_b && an_leader[s]) {
+              if (d >= 0) P.a_neg[(size_t)d * H + an_head[s]] = an[s];
+              else P.slots[(size_t)(-(d + 1)) * P.slot_stride + P.HF + 2 * H + an_head[s]] = an[s];
+            }
+            an[s] = 0.f;
           }
         }
       }
@@ -794,7 +839,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
               }
             }
 #pragma unroll
-            for (int s = 0; s < NS; ++s) acc_edge<NEG, VEC>(acc[s], accn[s], w[s], x[s]);
+            for (int s = 0; s < NS; ++s) acc_edge<NEG, VEC>(acc[s], accn[s], an[s], w[s], x[s]);
             if (ci & DGNN_ROWEND) {
               const int d = uniform_i32(dq[q]);
               ++q;
@@ -821,6 +866,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                   for (int s = 0; s < NS; ++s) {
                     if (active[s]) *(vec_t *)(dn + lane_off[s]) = accn[s];
                     accn[s] = V::zero();
+                    if (!an_in_b && an_leader[s]) {
+                      if (d >= 0) P.a_neg[(size_t)d * H + an_head[s]] = an[s];
+                      else P.slots[(size_t)(-(d + 1)) * P.slot_stride + P.HF + 2 * H + an_head[s]] = an[s];
+                    }
+                    an[s] = 0.f;
                   }
                 }
               }

@@ -186,8 +186,8 @@ std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, 
   // (appended to the list; two undefined tensors = None where the kernels have no such pair)
   Tensor out_neg, a_neg;
   if (neg && d.m > 0 && d.f % 4 == 0) {
-    out_neg = new_f32({d.m, d.h, d.f}, in_feat);
-    a_neg = new_f32({d.m, d.h}, in_feat);
+    out_neg = out_f32(outs, 3, {d.m, d.h, d.f}, in_feat, "out_neg");
+    a_neg = out_f32(outs, 4, {d.m, d.h}, in_feat, "a_neg");
   }
   int rc = API(dgnn_gat_forward)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope, fp(attn_row),
                                  fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), fp(edge_mask), fo(edge_max),
@@ -498,7 +498,8 @@ py::object gat_backward_seeded_dev(double negative_slope, double attn_drop, cons
 py::object gat_backward_packed(double negative_slope, double attn_drop, const Tensor &row_ptr, const Tensor &col_ind,
                                const Tensor &col_ptr, const Tensor &row_ind, const Tensor &permute,
                                const Tensor &row_stat, const OptTensor &edge_mask, const Tensor &in_feat,
-                               const Tensor &attn_col, const Tensor &grad, const OutList &outs) {
+                               const Tensor &attn_col, const Tensor &grad, const OutList &outs,
+                               bool need_grad_attn_row) {
   i32(row_ptr, "row_ptr"), i32(col_ind, "col_ind"), i32(col_ptr, "col_ptr"), i32(row_ind, "row_ind");
   i32(permute, "permute");
   f32(row_stat, "row_stat", 3), f32(in_feat, "in_feat", 3), f32(attn_col, "attn_col", 2), f32(grad, "grad", 3);
@@ -517,7 +518,7 @@ py::object gat_backward_packed(double negative_slope, double attn_drop, const Te
   }
   c10::DeviceGuard guard(in_feat.device());
   Tensor grad_feat = out_f32(outs, 0, {n, h, f}, in_feat, "grad_feat");
-  Tensor grad_attn_row = out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row");
+  Tensor grad_attn_row = need_grad_attn_row ? out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row") : Tensor();
   Tensor grad_attn_col = out_f32(outs, 2, {n, h}, in_feat, "grad_attn_col");
   const size_t nb = API(dgnn_gat_backward_workspace_bytes)(m, n, nnz, h, f, 1);
   Tensor ws = workspace(nb, in_feat);
@@ -996,7 +997,7 @@ PYBIND11_MODULE(fused_gatconv, m) {
       "-> [grad_feat, grad_attn_row, grad_attn_col], or None where the packed kernels do not apply.",
       arg("negative_slope"), arg("attn_drop"), arg("row_ptr"), arg("col_ind"), arg("col_ptr"), arg("row_ind"),
       arg("permute"), arg("row_stat"), arg("edge_mask"), arg("in_feat"), arg("attn_col"), arg("grad"),
-      arg("out") = py::none());
+      arg("out") = py::none(), arg("need_grad_attn_row") = true);
 }
 
 PYBIND11_MODULE(fused_gmmconv, m) {

@@ -69,10 +69,17 @@ class _NativeOps:
         self._gat = fused_gatconv
         self._fmt = format_conversion
 
-    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=None):
-        out, emax, esum, _ = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0,
-                                                   out=out)
-        return out, emax, esum
+    supports_neg = True     # the forward can return the negative-score pair (include/dgnn_hip.h)
+
+    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=None, neg=False):
+        """-> (out, edge_max, edge_sum) or, with neg, (+ out_neg, a_neg; None where unsupported);
+        out = (out, edge_max, edge_sum[, None, out_neg, a_neg]) views to write into."""
+        if not neg:
+            out, emax, esum, _ = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0,
+                                                       out=out)
+            return out, emax, esum
+        res = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0, out=out, neg=True)
+        return res[0], res[1], res[2], res[4], res[5]
 
     def row_dot(self, grad, out):
         return self._gat.gat_row_dot(grad, out)
@@ -83,10 +90,11 @@ class _NativeOps:
                                       edge_sum, None, in_feat, attn_row, attn_col, grad, row_dot=row_dot, out=out)
 
     def gat_backward_packed(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat, in_feat,
-                            attn_col, grad, out=None):
+                            attn_col, grad, out=None, need_grad_attn_row=True):
         """row_stat [rows,H,4] = {attn_row, edge_max, edge_sum, row_dot}; None where unsupported."""
         return self._gat.gat_backward_packed(slope, 0.0, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat,
-                                             None, in_feat, attn_col, grad, out=out)
+                                             None, in_feat, attn_col, grad, out=out,
+                                             need_grad_attn_row=need_grad_attn_row)
 
     def pack_rows(self, src, idx):
         """src[idx] (int32 idx) by the pack kernel: one float4 per lane, four loads in flight."""
@@ -433,13 +441,25 @@ class PartitionedGAT:
             out = torch.empty((self.n_loc,) + tuple(in_feat_loc.shape[1:]), dtype=in_feat_loc.dtype, device=in_feat_loc.device)
             emax = torch.empty((self.n_loc, h), dtype=in_feat_loc.dtype, device=in_feat_loc.device)
             esum = torch.empty_like(emax)
+            # the negative-score pair: grad_attn_row then needs nothing from other ranks (backward)
+            want_neg = getattr(self.ops, "supports_neg", False) and in_feat_loc.size(-1) % 4 == 0
+            out_neg = torch.empty_like(out) if want_neg else None
+            a_neg = torch.empty_like(emax) if want_neg else None
             for s, (a, b, ptr, ind, n_vis) in enumerate(side.blocks):   # every chunk writes its own rows
                 self._wait(handles[s])
-                self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
-                                     out=(out[a:b], emax[a:b], esum[a:b]))
+                if want_neg:
+                    res = self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
+                                               out=(out[a:b], emax[a:b], esum[a:b], out_neg[a:b], a_neg[a:b]), neg=True)
+                    if res[3] is None:             # shape outside the pair's kernels: the edge-gradient path
+                        want_neg, out_neg, a_neg = False, None, None
+                else:
+                    self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
+                                         out=(out[a:b], emax[a:b], esum[a:b]))
+            self._neg = (out_neg, a_neg) if want_neg else None
         else:
             in_tab, ac_tab = self._all_gather_rows(in_feat_loc), self._all_gather_rows(attn_col_loc)
             out, emax, esum = self.ops.gat_forward(attn_row_loc, ac_tab, self.f_row_ptr, self.f_col_ind, slope, in_tab)
+            self._neg = None
         self._ctx = (in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope)
         return out
 
@@ -457,7 +477,15 @@ class PartitionedGAT:
         else:
             grad_tab, stat_tab = self._all_gather_rows(grad_out_loc), self._all_gather_rows(stat_loc)
             handles = [[]]
-        gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
+        # With the forward's negative-score pair a row's owner computes grad_attn_row alone:
+        #   (1 - slope) (S * a_neg - <grad, out_neg>)      (include/dgnn_hip.h, dgnn_gat_forward)
+        # so the column chunks produce no edge gradients and no partial rows travel back.
+        local_gr = None
+        if self.mode == "halo" and getattr(self, "_neg", None) is not None:
+            out_neg, a_neg = self._neg
+            local_gr = (1.0 - slope) * (S_loc * a_neg - self.ops.row_dot(grad_out_loc, out_neg))
+        gr_tab = None if local_gr is not None else \
+            torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
         gf = torch.empty_like(in_feat_loc)
         gc = torch.empty_like(attn_col_loc)
         for s, (a, b, cptr, rind, n_vis, rptr, cind, perm) in enumerate(self.b_blocks):
@@ -465,6 +493,14 @@ class PartitionedGAT:
             # every chunk writes its own columns of grad_feat / grad_attn_col; its grad_attn_row
             # is a partial sum over the table rows it can see
             outs = (gf[a:b], None, gc[a:b])
+            if local_gr is not None:
+                res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],
+                                                   in_feat_loc[a:b], attn_col_loc[a:b], grad_tab[:n_vis], out=outs,
+                                                   need_grad_attn_row=False)
+                if res is not None:
+                    continue
+                local_gr = None             # (cannot happen for shapes the pair exists for; keep the old path whole)
+                gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
             res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],
                                                in_feat_loc[a:b], attn_col_loc[a:b], grad_tab[:n_vis], out=outs)
             if res is None:             # shape outside the packed kernels: unpack to four [rows,H] arrays
@@ -472,7 +508,9 @@ class PartitionedGAT:
                 res = self.ops.gat_backward(slope, rptr, cind, cptr, rind, perm, stat[1], stat[2], in_feat_loc[a:b],
                                             stat[0], attn_col_loc[a:b], grad_tab[:n_vis], stat[3], out=outs)
             gr_tab[:n_vis] += res[1]
-        if self.mode == "halo":
+        if local_gr is not None:
+            gr = local_gr
+        elif self.mode == "halo":
             gr = self._return_rows(self.b_side, gr_tab)
         else:
             if not self._solo:

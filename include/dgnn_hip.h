@@ -178,7 +178,11 @@ int dgnn_gat_backward(int m, int n, int nnz, int h, int f, float negative_slope,
  * fused_gatconv_kernel.cu:892-968, re-gathers the four arrays per edge).  Same outputs, bit for
  * bit, and same workspace (query with have_row_term = 1).  DGNN_ERR_UNSUPPORTED where the
  * neighbour-grouped kernels do not apply (h > 8, wide or misaligned rows, row_stat not 16-byte
- * aligned): unpack and call dgnn_gat_backward. */
+ * aligned): unpack and call dgnn_gat_backward.
+ * grad_attn_row may be NULL (here and in dgnn_gat_backward, neighbour-grouped kernels only): the
+ * caller derives it from the forward's negative-score pair, grad_attn_row = (1 - slope)(row_dot *
+ * a_neg - <grad, out_neg>) -- all per-row data the row's owner holds -- and no edge gradients are
+ * produced at all. */
 int dgnn_gat_backward_packed(int m, int n, int nnz, int h, int f, float negative_slope,
                              float attn_drop, const int *row_ptr, const int *col_ind,
                              const int *col_ptr, const int *row_ind, const int *permute,
