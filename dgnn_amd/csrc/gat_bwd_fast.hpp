@@ -148,6 +148,48 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
   }
 }
 
+// The same for rows of at most 32 float4 slots: S = lanes per row (a power of two >= H * fv),
+// 64 / S rows per load step and four steps per wave with all their loads issued before the first
+// reduction.  One wave per row left most lanes idle and the pass bound by waves launched
+// (profiles/r2d_*gatneg_1x64_products: 0.96 ms for 2.2 GB).
+__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat_packed(BwdParams P, int S) {
+  constexpr int STEPS = 4;
+  const int G = DGNN_WAVE / S;
+  const int lane = lane_id();
+  const int sl = lane % S, gi = lane / S;
+  const long long r0 = (long long)(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) * G * STEPS;
+  if (r0 >= P.m) return;
+  const BwdLane ln = bwd_lane<4>(P, sl, 0);
+  const bool need_g = P.S_in == nullptr || P.out_neg != nullptr;
+  float4 g[STEPS], o[STEPS], on[STEPS];
+  bool ok[STEPS];
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const long long r = r0 + k * G + gi;
+    ok[k] = ln.active && r < P.m;
+    g[k] = o[k] = on[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok[k]) {
+      const size_t at = (size_t)r * P.HF + ln.off;
+      if (need_g) g[k] = *(const float4 *)(P.grad + at);
+      if (P.S_in == nullptr) o[k] = *(const float4 *)(P.out_feat + at);
+      if (P.out_neg != nullptr) on[k] = *(const float4 *)(P.out_neg + at);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) {
+    const long long r = r0 + k * G + gi;
+    float s, gn = 0.f;
+    if (P.S_in == nullptr) s = group_reduce(vec_dot<4>(g[k], o[k]), P.fv, OpSum());
+    else s = ok[k] ? P.S_in[(size_t)r * P.H + ln.head] : 0.f;
+    if (P.out_neg != nullptr) gn = group_reduce(vec_dot<4>(g[k], on[k]), P.fv, OpSum());
+    if (ok[k] && ln.leader) {
+      const size_t i = (size_t)r * P.H + ln.head;
+      P.rowstat[i] = make_float4(P.attn_row[i], P.edge_max[i], P.edge_sum[i], s);
+      if (P.out_neg != nullptr) P.grad_attn_row[i] = (1.f - P.slope) * fmaf(s, P.a_neg[i], -gn);
+    }
+  }
+}
+
 // Column bookkeeping: empty columns are finished here, every group learns its first column.
 __global__ void k_bwd_prep_cols(BwdParams P) {
   for (long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x; c < P.n;

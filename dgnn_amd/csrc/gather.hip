@@ -558,7 +558,13 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.task_col0 = (int *)(ws + w.off_cols);
     P.slots = (float *)(ws + w.off_slots);
     if (m > 0 && !packed) {
-      if (vec == 4)
+      int rs = 1;
+      while (rs < h * P.fv) rs <<= 1;
+      if (vec == 4 && rs <= 32 && env_int("DGNN_ROWSTAT_PACKED", 1) != 0) {
+        const long long rows_per_wave = (long long)(DGNN_WAVE / rs) * 4;
+        hipLaunchKernelGGL(k_bwd_rowstat_packed, dim3(blocks_for_waves((m + rows_per_wave - 1) / rows_per_wave)),
+                           dim3(DGNN_BLOCK), 0, st, P, rs);
+      } else if (vec == 4)
         hipLaunchKernelGGL(k_bwd_rowstat<4>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
       else
         hipLaunchKernelGGL(k_bwd_rowstat<1>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);

@@ -6,6 +6,7 @@ tools/profile_ops.py <name>): a few launches of ONE operator family at its BASEL
                             the four DGCNN widths
   sddmm_spmm                mhsddmm + spmm_csr on the Reddit shape, 4 x 64
   gat_1x64_products / gat_8x8_products / gat_1x64_reddit   narrow fused GAT fwd + bwd
+  gatneg_<HxF>_<workload>                                  the same on the operator's negative-score path
   layer_products            whole GATConv layer (in = 100, 4 x 64, ELU, bias) fwd + bwd and an eval forward:
                             what the score / epilogue kernels around the operator cost"""
 import os
@@ -88,7 +89,8 @@ def sddmm_spmm():
         mhsddmm.mhsddmm(g["row_ptr"], g["col_ind"], go, x)
 
 
-def gat(H, F, workload):
+def gat(H, F, workload, neg=False):
+    """neg: the operator's path (forward writes the negative-score pair, the backward reads it)."""
     from dgnn_amd.native import fused_gatconv as fg
     g = bench.build_graph(workload, dev)
     n = g["n"]
@@ -96,9 +98,13 @@ def gat(H, F, workload):
     ar, ac = torch.rand((n, H), device=dev) - 0.6, torch.rand((n, H), device=dev) - 0.4
     go = torch.rand((n, H, F), device=dev) - 0.5
     for _ in range(REPS):
-        out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
+        on = an = None
+        if neg:
+            out, emax, esum, emask, on, an = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=True)
+        else:
+            out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
         fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], emax, esum,
-                        emask, x, ar, ac, go, out_feat=out)
+                        emask, x, ar, ac, go, out_feat=out, out_neg=on, a_neg=an)
 
 
 def layer(workload):
@@ -131,10 +137,10 @@ if __name__ == "__main__":
         sddmm_spmm()
     elif w.startswith("layer_"):
         layer(w[6:])
-    elif w.startswith("gat_"):
-        _, hf, wl = w.split("_")
+    elif w.startswith("gat_") or w.startswith("gatneg_"):
+        kind, hf, wl = w.split("_")
         h, f = hf.split("x")
-        gat(int(h), int(f), wl)
+        gat(int(h), int(f), wl, neg=kind == "gatneg")
     else:
         raise SystemExit(f"unknown operator set {w}")
     torch.cuda.synchronize()
