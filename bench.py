@@ -126,7 +126,7 @@ def algorithmic_bytes(n, nnz, h, f, neg=True):
 
 def measured_traffic(workload, kernel_name):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
-    of this workload (profiles/*pmc_hbm_bytes_<workload>.csv: FETCH_SIZE and WRITE_SIZE collected
+    of this workload (profiles/*pmc_hbm_bytes_<workload>.csv, the last by tag name: FETCH_SIZE and WRITE_SIZE collected
     in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM
     prescribes for gfx950).  Counters cannot be read from inside the process, so the figure is
     only as fresh as that profile: it is returned with the file it came from, and it is None when
@@ -135,7 +135,7 @@ def measured_traffic(workload, kernel_name):
     kernel has changed since.  -> (bytes or None, source file or None)"""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_hbm_bytes_{workload}.csv")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_hbm_bytes_{workload}.csv")))   # r1_a < ... < r2d: newest tag last
     if not files or not kernel_name:
         return None, None
     src = files[-1]

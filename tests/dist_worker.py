@@ -3,6 +3,9 @@
 mode "cpu": gloo backend, CPU tensors, compute through a CPU stand-in built on the oracle
             (test infrastructure: exercises the partition, block extraction, inverse
             permutation and collectives without a GPU).
+mode "cpuneg": the same with a stand-in that also produces the forward's negative-score pair, so the
+            runner takes the path on which a row's owner computes grad_attn_row alone (no return
+            exchange; dgnn_amd/dist.py).
 mode "gpu": gloo backend, every rank on cuda:0, compute through the real HIP kernels.
 mode "nccl1": ONE rank on cuda:0 with the nccl (= RCCL) backend and DGNN_DIST_FORCE_COLLECTIVES=1:
             every collective of the step is really issued through RCCL (RCCL wants one GPU per
@@ -94,6 +97,39 @@ class OracleOps:
         return self._emit((self._t(gf, np.float32), self._t(gr, np.float32), self._t(gc, np.float32)), out)
 
 
+class OracleOpsNeg(OracleOps):
+    """The stand-in with the negative-score pair of include/dgnn_hip.h (dgnn_gat_forward): out_neg =
+    the aggregate over the edges whose pre-activation score is negative, a_neg = the sum of their
+    softmax weights; the packed backward can be asked to leave grad_attn_row out."""
+    supports_neg = True
+
+    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=None, neg=False):
+        base = super().gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat)
+        if not neg:
+            return self._emit(base, out)
+        rp, ci = row_ptr.numpy().astype(np.int64), col_ind.numpy().astype(np.int64)
+        row = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+        e0 = attn_row.double().numpy()[row] + attn_col.double().numpy()[ci]
+        e = np.where(e0 > 0, e0, e0 * slope)
+        a = np.exp(e - base[1].double().numpy()[row]) / base[2].double().numpy()[row]
+        an_e = np.where(e < 0, a, 0.0)
+        a_neg = np.zeros((rp.size - 1, e.shape[1]))
+        np.add.at(a_neg, row, an_e)
+        out_neg = np.zeros((rp.size - 1,) + tuple(in_feat.shape[1:]))
+        np.add.at(out_neg, row, an_e[:, :, None] * in_feat.double().numpy()[ci])
+        return self._emit(base + (self._t(out_neg, np.float32), self._t(a_neg, np.float32)), out)
+
+    def gat_backward_packed(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat, in_feat,
+                            attn_col, grad, out=None, need_grad_attn_row=True):
+        if need_grad_attn_row:
+            return super().gat_backward_packed(slope, row_ptr, col_ind, col_ptr, row_ind, permute, row_stat,
+                                               in_feat, attn_col, grad, out=out)
+        st = row_stat.permute(2, 0, 1).contiguous()
+        gf, _, gc = self.gat_backward(slope, row_ptr, col_ind, col_ptr, row_ind, permute, st[1], st[2], in_feat,
+                                      st[0], attn_col, grad, st[3])
+        return self._emit((gf, None, gc), out)
+
+
 def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -106,9 +142,9 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     from dgnn_amd.dist import PartitionedGAT
     g = rmat_graph(*graph_spec)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
-    device = torch.device("cpu" if mode == "cpu" else "cuda:0")
+    device = torch.device("cpu" if mode in ("cpu", "cpuneg") else "cuda:0")
     G = {k: torch.from_numpy(g[k]).to(device) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
-    ops = OracleOps() if mode == "cpu" else None
+    ops = OracleOps() if mode == "cpu" else OracleOpsNeg() if mode == "cpuneg" else None
     runner = PartitionedGAT(G, world, rank, device, ops=ops)
     lo, hi = runner.lo, runner.hi
     t = lambda a: torch.from_numpy(a).to(device)
@@ -118,6 +154,8 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     x_loc.copy_(t(in_feat[lo:hi]))
     out = runner.forward(x_loc, t(attn_row[lo:hi]), t(attn_col[lo:hi]), 0.2)
     gf, gr, gc = runner.backward(t(grad[lo:hi]))
+    if mode == "cpuneg" and runner.mode == "halo":
+        assert runner._neg is not None, "the stand-in offers the pair: the runner must take the owner-local path"
     if device.type == "cuda":
         torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, out=out.cpu().numpy(),

@@ -86,6 +86,15 @@ def test_partitioned_gat_cpu_gloo_chunked_pipeline(world, chunks):
     check(run_world(world, "cpu", spec, h, f, "halo", chunks), spec, h, f)
 
 
+@pytest.mark.parametrize("world,chunks", [(2, None), (3, 2), (4, 1)])
+def test_partitioned_gat_cpu_gloo_owner_local_grad_attn_row(world, chunks):
+    """With the forward's negative-score pair a row's owner computes grad_attn_row from its own
+    tensors: the column chunks return no partial rows and no return exchange runs
+    (dgnn_amd/dist.py: backward).  Same results as the returning path."""
+    spec, h, f = (10, 700, 6000, 5), 2, 8
+    check(run_world(world, "cpuneg", spec, h, f, "halo", chunks), spec, h, f)
+
+
 def test_chunk_fractions_and_incremental_tables():
     import torch
     from dgnn_amd.dist import PartitionedGAT, chunk_fractions
