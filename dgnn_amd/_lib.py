@@ -65,6 +65,8 @@ SIGNATURES = {
     "dgnn_csr2csc": (_i, [_i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_coo2csr": (_i, [_i, _i] + [_vp] * 2 + [_vp]),
     "dgnn_knn_graph": (_i, [_i, _i, _i, _i] + [_vp] * 2 + [_vp]),
+    "dgnn_knn_graph_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dgnn_knn_graph_ws": (_i, [_i, _i, _i, _i] + [_vp] * 2 + [_vp, _sz, _vp]),
     "dgnn_gat_attn_scores": (_i, [_i, _i, _i] + [_vp] * 5 + [_vp]),
     "dgnn_gat_attn_scores_backward_workspace_bytes": (_sz, [_i, _i, _i]),
     "dgnn_gat_attn_scores_backward": (_i, [_i, _i, _i] + [_vp] * 8 + [_vp, _sz, _vp]),

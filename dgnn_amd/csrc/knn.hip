@@ -23,6 +23,12 @@
 namespace dgnn {
 namespace {
 
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 template <int KMAX, bool MED3>
 struct TopK {
   float d[KMAX];
@@ -107,8 +113,11 @@ template <int KMAX, int FC, bool SINGLE>
 __global__ __launch_bounds__(64 * KNN_MAX_PARTS)
 void k_knn(int points, int dim, int k, int tj,
                                                     const float *__restrict__ x,
-                                                    int *__restrict__ src_ind) {
+                                                    int *__restrict__ src_ind,
+                                                    const int *__restrict__ block_flags) {
   extern __shared__ __align__(16) float lds[];
+  // second stage of the filtered path (below): only the query blocks it could not certify
+  if (block_flags != nullptr && block_flags[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
   const int part = wave_in_block(), lane = lane_id();
   const int KNN_PARTS = (int)(blockDim.x >> 6);            // waves of this block = parts of the cloud
   float *tile = lds + (size_t)part * tj * FC;                                   // [tj][FC]
@@ -235,7 +244,8 @@ static int knn_allow_lds(const void *fn, size_t bytes) {
 }
 
 template <int KMAX>
-int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_ind, hipStream_t st) {
+int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_ind, hipStream_t st,
+               const int *block_flags = nullptr) {
   const dim3 grid((unsigned)((points + 63) / 64), (unsigned)batch);
   // Parts per query block: each part keeps its own sorted list, so fewer parts mean fewer list
   // insertions in total, but the chip wants its two resident waves per SIMD (2048 waves) and no
@@ -254,7 +264,7 @@ int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_i
     if (int rc = knn_allow_lds((const void *)k_knn<KMAX, FCV, true>, knn_lds_bytes(FCV, true, k, parts)))  \
       return rc;                                                                                    \
     hipLaunchKernelGGL((k_knn<KMAX, FCV, true>), grid, block, knn_lds_bytes(FCV, true, k, parts), st, points, \
-                       dim, k, knn_tile(FCV), x, src_ind);                                          \
+                       dim, k, knn_tile(FCV), x, src_ind, block_flags);                             \
     DGNN_LAUNCH_CHECK();                                                                            \
     return DGNN_OK;                                                                                 \
   }
@@ -266,9 +276,613 @@ int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_i
 #undef DGNN_KNN_CASE
   if (int rc = knn_allow_lds((const void *)k_knn<KMAX, 128, false>, knn_lds_bytes(128, false, k, parts))) return rc;
   hipLaunchKernelGGL((k_knn<KMAX, 128, false>), grid, block, knn_lds_bytes(128, false, k, parts), st, points, dim,
-                     k, knn_tile(128), x, src_ind);
+                     k, knn_tile(128), x, src_ind, block_flags);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Filtered path for 17 .. 128 dims: a coarse candidate filter on the matrix cores in front of the
+// exact chain.  The ids stay bit-exact: the filter only decides WHICH
+// candidates get their exact fma-chain distance, and a query whose result the filter cannot
+// certify is redone by k_knn above.
+//
+//   1. k_knn_split: every point as two bf16 vectors x = xh + xl (+ residual <= 2^-16 |x|), plus
+//      nyk = (1 - c) ||x||^2 (float32), per cloud padded to a multiple of 32 points (zero vectors,
+//      nyk = +inf).
+//   2. k_knn_mfma: a wave owns 32 queries (the B operand of v_mfma_f32_32x32x16_bf16, one query per
+//      lane column, held in registers) and walks the cloud in tiles of 32 candidates (A operand,
+//      16-byte loads straight from the split arrays in fragment layout: no LDS staging);
+//      P = xh.yh + xh.yl + xl.yh accumulates in float32, three MFMAs per 16 dims.  Each lane gets
+//      16 candidates of its query per tile and keeps the KL smallest keys
+//          key_j = (1 - c) ny_j - 2 P_j       (+ (1 - c) nx = a LOWER BOUND of the exact chain
+//                                               distance d_ij: |ny + nx - 2P - d_ij| <= c (nx + ny_j))
+//      in a sorted register list (same queue + insertion as the exact kernel); the two lanes of a
+//      query (rows 4h .. 4h+3 of every 8) merge at the end.  KL > k leaves slack.
+//   3. k_knn_rerank: one lane per query computes the exact chain distance of its KL candidates,
+//      keeps the k best by (distance, id), and certifies the result: every candidate outside the
+//      list has chain distance >= key_last + (1 - c) nx; if the k-th exact distance is strictly
+//      below that bound nobody outside can enter or tie.  Otherwise (ties, duplicates, tiny gaps,
+//      non-finite input) the query's 64-query block is flagged and k_knn recomputes it.
+// c = 2^-11 covers, with a factor > 2 to spare, the split residual (3.1 * 2^-16 (nx+ny)), the
+// float32 accumulation of 3 * dim products (<= 3 * 2^-16 at 128 dims), the float32 norms and the
+// rounding of the exact chain itself ((dim + 2) * 2^-24 * d, d <= 2 (nx + ny)).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr float KNN_C = 1.0f / 2048.0f;
+constexpr int KNN_MQ = 32;            // queue entries per lane in k_knn_mfma
+
+__device__ __forceinline__ unsigned short bf16_rne(float v) {        // finite or not: NaN stays NaN
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// one thread per (padded point, group of 8 dims); the thread of group 0 also writes nyk
+__global__ void k_knn_split(int points, int pp, int dim, int dimp, const float *__restrict__ x,
+                            unsigned short *__restrict__ xh, unsigned short *__restrict__ xl,
+                            float *__restrict__ nyk, int *__restrict__ cloud_bad) {
+  const int groups = dimp >> 3;
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= (long long)pp * groups) return;
+  const int j = (int)(t / groups), g = (int)(t - (long long)j * groups);
+  const float *row = x + ((size_t)b * points + (j < points ? j : 0)) * dim;
+  unsigned short hi[8], lo[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int f = g * 8 + e;
+    const float v = (j < points && f < dim) ? row[f] : 0.f;
+    hi[e] = bf16_rne(v);
+    lo[e] = bf16_rne(v - __uint_as_float((unsigned)hi[e] << 16));
+  }
+  const size_t at = ((size_t)b * pp + j) * dimp + (size_t)g * 8;
+  *(uint4 *)(xh + at) = make_uint4(hi[0] | (unsigned)hi[1] << 16, hi[2] | (unsigned)hi[3] << 16,
+                                   hi[4] | (unsigned)hi[5] << 16, hi[6] | (unsigned)hi[7] << 16);
+  *(uint4 *)(xl + at) = make_uint4(lo[0] | (unsigned)lo[1] << 16, lo[2] | (unsigned)lo[3] << 16,
+                                   lo[4] | (unsigned)lo[5] << 16, lo[6] | (unsigned)lo[7] << 16);
+  if (g == 0) {
+    float ny = __builtin_inff();
+    if (j < points) {
+      ny = 0.f;
+      for (int f = 0; f < dim; ++f) ny = fmaf(row[f], row[f], ny);
+      ny *= (1.f - KNN_C);
+      if (!(ny < __builtin_inff())) cloud_bad[b] = 1;      // inf or NaN: the filter certifies nothing here
+    }
+    nyk[(size_t)b * pp + j] = ny;
+  }
+}
+
+template <int KL, int NKK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL <= 32 ? 2 : 1, KL <= 32 ? 2 : 1)))
+void k_knn_mfma(int points, int pp, long long nq, const unsigned short *__restrict__ xh,
+                const unsigned short *__restrict__ xl, const float *__restrict__ nyk,
+                int *__restrict__ cand, float *__restrict__ key_last) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int DIMP = NKK * 16;
+  constexpr int PER_WAVE = (KL * 32 * 2 > KNN_MQ * 64 * 2) ? KL * 32 * 2 : KNN_MQ * 64 * 2;   // floats
+  const int wave = wave_in_block(), lane = lane_id();
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int q0 = uniform_i32((blockIdx.x * 4 + wave) * 32);
+  if (q0 >= points) return;                                  // no block-wide barrier below
+  float *qd = lds + (size_t)wave * PER_WAVE;                 // [KNN_MQ][64] keys
+  int *qi = (int *)(qd + KNN_MQ * 64);                       // [KNN_MQ][64] ids
+  const size_t base = (size_t)b * pp;
+  const bf16x8 *gh = (const bf16x8 *)xh, *gl = (const bf16x8 *)xl;   // 8 bf16 = 16 bytes
+  // fragment element index of (row, k-step kk, half h): (row * DIMP + 16 kk + 8 h) / 8
+  auto frag = [&](size_t row, int kk) { return row * (DIMP / 8) + 2 * kk + h; };
+  bf16x8 bh[NKK], bl[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    bh[kk] = gh[frag(base + q0 + r, kk)];
+    bl[kk] = gl[frag(base + q0 + r, kk)];
+  }
+  TopK<KL, true> best;
+  best.init();
+  int queued = 0;
+  float thr = __builtin_inff();
+  // One flush site per tile (a tile hands every lane 16 candidates): the queue holds KNN_MQ >= 32
+  // entries per lane and is emptied before a tile that might overflow it.  The acceptance
+  // threshold `thr` is refreshed after every flush (stale in between = a few more queue entries).
+  auto flush = [&]() {
+    for (int t = 0; t < KNN_MQ; ++t) {
+      if (!__any(t < queued)) break;
+      const bool have = t < queued;
+      best.push(have ? qd[t * 64 + lane] : __builtin_inff(), have ? qi[t * 64 + lane] : -1);
+    }
+    queued = 0;
+  };
+  auto load = [&](bf16x8 (&ah)[NKK], bf16x8 (&al)[NKK], int j0) {
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      ah[kk] = gh[frag(base + j0 + r, kk)];
+      al[kk] = gl[frag(base + j0 + r, kk)];
+    }
+  };
+  auto tile = [&](const bf16x8 (&ah)[NKK], const bf16x8 (&al)[NKK], int j0) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bh[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bl[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk], bh[kk], acc, 0, 0, 0);
+    }
+    if (__any(queued > KNN_MQ - 16)) {
+      flush();
+      // the two lanes of a query share their bound: a key at or above the KL-th smallest key of
+      // BOTH lists together cannot be among the KL smallest of the union later either
+      // exactly: the KL-th smallest key of the two lists together = min over s of
+      // max(A[s-1], B[KL-s-1]) (s entries from this lane's sorted list A, KL - s from the other's B)
+      float u = __shfl_xor(best.d[KL - 1], 32, 64);          // s = 0
+#pragma unroll
+      for (int sidx = 1; sidx < KL; ++sidx) {
+        const float bv = __shfl_xor(best.d[KL - sidx - 1], 32, 64);
+        u = fminf(u, fmaxf(best.d[sidx - 1], bv));
+      }
+      thr = fminf(u, best.d[KL - 1]);                         // s = KL
+    }
+    // register 4g + e = candidate row 8g + 4h + e of the tile, this lane's query column
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 n4 = *(const float4 *)(nyk + base + j0 + 8 * g + 4 * h);
+      const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float key = fmaf(-2.f, acc[4 * g + e], nn[e]);
+        if (key < thr) {
+          qd[queued * 64 + lane] = key;
+          qi[queued * 64 + lane] = j0 + 8 * g + 4 * h + e;
+          ++queued;
+        }
+      }
+    }
+  };
+  // two tiles per trip: the fragments of the next tile load while this one multiplies, and the
+  // two register sets swap roles without copies
+  if constexpr (NKK <= 4) {
+    bf16x8 a0h[NKK], a0l[NKK], a1h[NKK], a1l[NKK];
+    load(a0h, a0l, 0);
+    for (int j0 = 0; j0 < pp; j0 += 64) {
+      const bool two = j0 + 32 < pp;
+      if (two) load(a1h, a1l, j0 + 32);
+      tile(a0h, a0l, j0);
+      if (two) {
+        if (j0 + 64 < pp) load(a0h, a0l, j0 + 64);
+        tile(a1h, a1l, j0 + 32);
+      }
+    }
+  } else {           // 128 dims: one fragment set (two would not fit two waves per SIMD)
+    bf16x8 ah[NKK], al[NKK];
+    for (int j0 = 0; j0 < pp; j0 += 32) {
+      load(ah, al, j0);
+      tile(ah, al, j0);
+    }
+  }
+  flush();
+  // the two lanes of a query: the upper half hands its list over through LDS
+  wave_lds_sync();
+  float *md = lds + (size_t)wave * PER_WAVE;                 // [KL][32]
+  int *mi = (int *)(md + KL * 32);
+  if (h == 1) {
+#pragma unroll
+    for (int t = 0; t < KL; ++t) {
+      md[t * 32 + r] = best.d[t];
+      mi[t * 32 + r] = best.id[t];
+    }
+  }
+  wave_lds_sync();
+  if (h == 0) {
+    for (int t = 0; t < KL; ++t) {
+      const int jn = mi[t * 32 + r];
+      const float dn = md[t * 32 + r];
+      if (__any(jn >= 0)) best.push(jn >= 0 ? dn : __builtin_inff(), jn);
+    }
+    if (q0 + r < points) {
+      const long long gq = (long long)b * points + q0 + r;
+#pragma unroll
+      for (int t = 0; t < KL; ++t) cand[(size_t)t * nq + gq] = best.id[t];
+      key_last[gq] = best.d[KL - 1];
+    }
+  }
+}
+
+// exact (distance, id) order for candidates that arrive in any order
+template <int KMAX>
+struct TopKLex {
+  float d[KMAX];
+  int id[KMAX];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) { d[t] = __builtin_inff(); id[t] = -1; }
+  }
+  __device__ __forceinline__ void push(float dn, int jn) {
+    bool sw = false;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      const float td = d[t];
+      const int ti = id[t];
+      sw = sw || dn < td || (dn == td && jn >= 0 && ti >= 0 && jn < ti);
+      d[t] = sw ? dn : td;
+      id[t] = sw ? jn : ti;
+      dn = sw ? td : dn;
+      jn = sw ? ti : jn;
+    }
+  }
+};
+
+// A block = 64 queries (lane = query) x 4 waves; wave w evaluates the exact chain for list entries
+// w, w + 4, ...  A lane reading its own candidate row straight from memory makes every load
+// instruction touch 64 different lines: instead the wave copies the 64 rows of one list entry, 32
+// dims at a time, into a private LDS tile with coalesced 16-byte loads (8 rows x 128 B per
+// instruction; the next chunk's loads are in flight while this one is consumed) and every lane
+// reads ITS row from the tile.  The chain is carried across the chunks in a register, so the order
+// of operations is the exhaustive kernel's.  Selection is by RANK, not by insertion: entry t goes
+// to output slot #{u : (d_u, id_u) < (d_t, id_t)} -- kl^2 compares spread over the four waves.
+constexpr int KNN_CH = 32;                // dims per staged chunk
+constexpr int KNN_RS = KNN_CH + 4;        // tile row stride (floats): 16-byte reads of 16 lanes hit 16 bank groups
+constexpr int KNN_REDO_MAX = 4;           // flagged queries per 64-query block the wave-per-query pass takes
+
+// dims [f0, f0 + 32) of the rows `row_of_lane` (lane r names row r of the tile): global -> registers
+__device__ __forceinline__ void knn_fetch(float (&regs)[32], const float *xc, int row_of_lane, int dim, int f0,
+                                          bool vec4, int lane) {
+  if (vec4) {
+    const int p = lane & 7;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int j = __shfl(row_of_lane, (lane >> 3) + 8 * m, 64);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f0 + 4 * p < dim) v = *(const float4 *)(xc + (size_t)j * dim + f0 + 4 * p);
+      regs[4 * m + 0] = v.x; regs[4 * m + 1] = v.y; regs[4 * m + 2] = v.z; regs[4 * m + 3] = v.w;
+    }
+  } else {
+    const int e = lane & 31;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const int j = __shfl(row_of_lane, (lane >> 5) + 2 * m, 64);
+      regs[m] = (f0 + e < dim) ? xc[(size_t)j * dim + f0 + e] : 0.f;
+    }
+  }
+}
+// registers -> tile[64][KNN_RS]
+__device__ __forceinline__ void knn_put(float *tile, const float (&regs)[32], bool vec4, int lane) {
+  if (vec4) {
+    const int p = lane & 7;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      *(float4 *)(tile + ((lane >> 3) + 8 * m) * KNN_RS + 4 * p) =
+          make_float4(regs[4 * m + 0], regs[4 * m + 1], regs[4 * m + 2], regs[4 * m + 3]);
+  } else {
+    const int e = lane & 31;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) tile[((lane >> 5) + 2 * m) * KNN_RS + e] = regs[m];
+  }
+}
+
+template <int FC>
+__global__ __launch_bounds__(256)
+void k_knn_rerank(int points, int pp, int dim, int k, int kl, long long nq, const float *__restrict__ x,
+                  const float *__restrict__ nyk, const int *__restrict__ cand, float *__restrict__ key_last,
+                  const int *__restrict__ cloud_bad, int *__restrict__ src_ind, int *__restrict__ redo_flags,
+                  int *__restrict__ block_flags, int *__restrict__ query_flags, int redo_max) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = lane_id(), wave = wave_in_block(), b = blockIdx.y;
+  float *tile = lds + (size_t)wave * 64 * KNN_RS;             // wave-private [64][KNN_RS]
+  float *dl = lds + (size_t)4 * 64 * KNN_RS;                  // [kl][64] exact distances (+inf = no entry)
+  int *il = (int *)(dl + (size_t)kl * 64);                    // [kl][64] ids
+  float *dks = (float *)(il + (size_t)kl * 64);               // [64] k-th exact distance
+  const int i = blockIdx.x * 64 + lane;
+  const bool active = i < points;
+  const float *xc = x + (size_t)b * points * dim;
+  const long long gq = (long long)b * points + (active ? i : 0);
+  const bool vec4 = (dim & 3) == 0 && ((size_t)x & 15) == 0;
+  constexpr int NCH = FC / KNN_CH;
+  const int nch = (dim + KNN_CH - 1) / KNN_CH;                // chunks that hold data
+  float regs[32];
+  float xi[FC];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c < nch) {
+      knn_fetch(regs, xc, active ? i : 0, dim, c * KNN_CH, vec4, lane);
+      knn_put(tile, regs, vec4, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int f4 = 0; f4 < KNN_CH / 4; ++f4) {
+        const float4 v = *(const float4 *)(tile + lane * KNN_RS + 4 * f4);
+        xi[c * KNN_CH + 4 * f4 + 0] = v.x; xi[c * KNN_CH + 4 * f4 + 1] = v.y;
+        xi[c * KNN_CH + 4 * f4 + 2] = v.z; xi[c * KNN_CH + 4 * f4 + 3] = v.w;
+      }
+      wave_lds_sync();
+    } else {
+#pragma unroll
+      for (int f = 0; f < KNN_CH; ++f) xi[c * KNN_CH + f] = 0.f;
+    }
+  }
+  // the wave's list entries t = wave, wave + 4, ...; chunks in (t, c) order, one fetch ahead
+  int jt = (active && wave < kl) ? cand[(size_t)wave * nq + gq] : -1;
+  if (wave < kl) knn_fetch(regs, xc, jt >= 0 ? jt : 0, dim, 0, vec4, lane);
+  for (int t = wave; t < kl; t += 4) {
+    const int tn = t + 4;
+    const int jn = (active && tn < kl) ? cand[(size_t)tn * nq + gq] : -1;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c < nch) {
+        knn_put(tile, regs, vec4, lane);
+        wave_lds_sync();
+        if (c + 1 < nch) knn_fetch(regs, xc, jt >= 0 ? jt : 0, dim, (c + 1) * KNN_CH, vec4, lane);
+        else if (tn < kl) knn_fetch(regs, xc, jn >= 0 ? jn : 0, dim, 0, vec4, lane);
+#pragma unroll
+        for (int f4 = 0; f4 < KNN_CH / 4; ++f4) {
+          const float4 v = *(const float4 *)(tile + lane * KNN_RS + 4 * f4);
+          float u;       // padded dims hold 0 on both sides: fma(0,0,acc) == acc exactly
+          u = xi[c * KNN_CH + 4 * f4 + 0] - v.x; acc = fmaf(u, u, acc);
+          u = xi[c * KNN_CH + 4 * f4 + 1] - v.y; acc = fmaf(u, u, acc);
+          u = xi[c * KNN_CH + 4 * f4 + 2] - v.z; acc = fmaf(u, u, acc);
+          u = xi[c * KNN_CH + 4 * f4 + 3] - v.w; acc = fmaf(u, u, acc);
+        }
+        wave_lds_sync();
+      }
+    }
+    const bool ok = jt >= 0 && acc < __builtin_inff();          // NaN / inf: never a neighbour
+    dl[t * 64 + lane] = ok ? acc : __builtin_inff();
+    il[t * 64 + lane] = ok ? jt : -1;
+    jt = jn;
+  }
+  __syncthreads();
+  // rank of every entry among the kl of its query; entries without a candidate (d = +inf) rank
+  // behind all others in list order, so slots 0 .. k-1 are each written exactly once
+  {
+    int *o = src_ind + ((size_t)b * points + (active ? i : 0)) * k;
+    const int gbase = b * points;
+    for (int t = wave; t < kl; t += 4) {
+      const float dt = dl[t * 64 + lane];
+      const int idt = il[t * 64 + lane];
+      int rank = 0;
+      for (int u = 0; u < kl; ++u) {
+        const float du = dl[u * 64 + lane];
+        const int idu = il[u * 64 + lane];
+        const bool less = du < dt || (du == dt && (idt >= 0 ? idu < idt : u < t));
+        rank += less ? 1 : 0;
+      }
+      if (active && rank < k) o[rank] = gbase + (idt >= 0 ? idt : i);   // unfilled: the query itself
+      if (rank == k - 1) dks[lane] = dt;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  bool safe = true;
+  if (active) {
+    const float dk = dks[lane];
+    const float kl_key = key_last[gq], nx = nyk[(size_t)b * pp + i];
+    if (kl_key == __builtin_inff()) {
+      safe = true;                      // the list never filled: every candidate with a finite key is in it
+    } else {
+      const float bound = kl_key + nx;
+      const float slack = 3.8e-6f * (fabsf(kl_key) + nx);          // 2^-18: rounding of key and bound
+      safe = dk < bound - slack;                                   // false for NaN
+    }
+    if (cloud_bad[b] != 0) safe = false;
+    query_flags[gq] = safe ? 0 : 1;
+    key_last[gq] = dk;                  // for k_knn_redo: every true neighbour is at most this far
+  }
+  const int nbad = __popcll(__ballot(!safe));
+  if (lane == 0) {
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    redo_flags[blk] = (nbad > 0 && nbad <= redo_max) ? 1 : 0;      // few: k_knn_redo, query by query
+    block_flags[blk] = nbad > redo_max ? 1 : 0;                    // many (ties everywhere): k_knn
+  }
+}
+
+// The few queries the filter could not certify, one BLOCK pass per query: the list's k-th exact
+// distance bounds every true neighbour, so the 256 lanes evaluate the exact chain for all of the
+// cloud's candidates, keep those within the bound (k plus a handful), and rank them by (distance,
+// id).  More survivors than the buffer holds (a cloud of exact ties) hands the block to k_knn.
+constexpr int KNN_REDO_CAP = 1024;
+template <int FC>
+__global__ __launch_bounds__(256)
+void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const int *__restrict__ redo_flags,
+                const int *__restrict__ query_flags, const float *__restrict__ dk_bound,
+                int *__restrict__ block_flags, int *__restrict__ src_ind) {
+  __shared__ float sd[KNN_REDO_CAP];
+  __shared__ int sj[KNN_REDO_CAP];
+  __shared__ int cnt;
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (redo_flags[blk] == 0) return;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const float *xc = x + (size_t)b * points * dim;
+  const bool vec4 = (dim & 3) == 0 && ((size_t)x & 15) == 0;
+  for (int q = 0; q < 64; ++q) {
+    const int i = blockIdx.x * 64 + q;
+    if (i >= points) break;
+    const size_t gq = (size_t)b * points + i;
+    if (uniform_i32(query_flags[gq]) == 0) continue;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    const float dk = dk_bound[gq];
+    float xi[FC];
+#pragma unroll
+    for (int f = 0; f < FC; ++f) xi[f] = (f < dim) ? xc[(size_t)i * dim + f] : 0.f;
+    for (int c = tid; c < points; c += 256) {
+      const float *cj = xc + (size_t)c * dim;
+      float acc = 0.f;
+      if (vec4) {
+#pragma unroll
+        for (int f4 = 0; f4 < FC / 4; ++f4) {
+          if (4 * f4 < dim) {
+            const float4 v = *(const float4 *)(cj + 4 * f4);
+            float u;
+            u = xi[4 * f4 + 0] - v.x; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 1] - v.y; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 2] - v.z; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 3] - v.w; acc = fmaf(u, u, acc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < FC; ++f) {
+          if (f < dim) {
+            const float u = xi[f] - cj[f];
+            acc = fmaf(u, u, acc);
+          }
+        }
+      }
+      if (acc <= dk && acc < __builtin_inff()) {              // NaN / inf: never a neighbour
+        const int slot = atomicAdd(&cnt, 1);
+        if (slot < KNN_REDO_CAP) { sd[slot] = acc; sj[slot] = c; }
+      }
+    }
+    __syncthreads();
+    const int m = cnt;
+    if (m > KNN_REDO_CAP) {              // block-uniform: the exhaustive kernel takes the whole block
+      if (tid == 0) block_flags[blk] = 1;
+      return;
+    }
+    int *o = src_ind + gq * k;
+    const int gbase = b * points;
+    for (int t = tid; t < m; t += 256) {
+      const float dt = sd[t];
+      const int jt = sj[t];
+      int rank = 0;
+      for (int u = 0; u < m; ++u) {
+        const float du = sd[u];
+        const int ju = sj[u];
+        rank += (du < dt || (du == dt && ju < jt)) ? 1 : 0;
+      }
+      if (rank < k) o[rank] = gbase + jt;
+    }
+    for (int t = m + tid; t < k; t += 256) o[t] = gbase + i;     // fewer finite candidates than k
+    __syncthreads();
+  }
+}
+
+struct KnnWs {
+  size_t off_xh, off_xl, off_nyk, off_cand, off_key, off_bad, off_flags, off_qflags, off_rflags, total;
+  int pp, dimp, kl;
+};
+// list length of the filter: k + at least 4 spare candidates.  Cost grows with KL^2 (accepted
+// candidates ~ KL ln(N / KL), each a pass over KL slots); a thin margin only means more query
+// blocks handed to the exhaustive kernel on data with near-ties.
+static inline int knn_filter_list(int k) { return k <= 20 ? 24 : (k <= 28 ? 32 : (k <= 44 ? 48 : (k <= 60 ? 64 : 0))); }
+static KnnWs knn_ws_layout(int batch, int points, int dim, int k) {
+  KnnWs w = {};
+  w.kl = knn_filter_list(k);
+  w.pp = (points + 31) / 32 * 32;
+  w.dimp = dim <= 32 ? 32 : (dim <= 64 ? 64 : 128);     // k-steps of 16: 2, 4 or 8 per tile
+  const size_t nq = (size_t)batch * points, np = (size_t)batch * w.pp;
+  size_t o = 0;
+  auto seg = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+  w.off_xh = seg(np * w.dimp * 2);
+  w.off_xl = seg(np * w.dimp * 2);
+  w.off_nyk = seg(np * 4);
+  w.off_cand = seg(nq * (size_t)w.kl * 4);
+  w.off_key = seg(nq * 4);
+  w.off_bad = seg((size_t)batch * 4);
+  w.off_flags = seg((size_t)batch * ((points + 63) / 64) * 4);
+  w.off_qflags = seg(nq * 4);
+  w.off_rflags = seg((size_t)batch * ((points + 63) / 64) * 4);
+  w.total = o;
+  return w;
+}
+// The filter pays when the exact chain dominates (more than 16 dims) and the problem fills the
+// chip with 32-query waves; everything else stays on the exact kernel alone.
+static bool knn_filter_applies(int batch, int points, int dim, int k) {
+  if (env_int("DGNN_KNN_FILTER", 1) == 0) return false;
+  if (dim <= 16 || dim > 128 || knn_filter_list(k) == 0) return false;
+  if (knn_filter_list(k) > 32 && dim <= 64) return false;    // long lists run one wave per SIMD: the chain must dominate
+  if (points < 2 * knn_filter_list(k)) return false;
+  return (long long)batch * ((points + 31) / 32) >= env_int("DGNN_KNN_FILTER_MIN_WAVES", 512);
+}
+
+template <int KL>
+static int launch_knn_mfma(int nkk, dim3 grid, size_t lds, hipStream_t st, int points, int pp, long long nq,
+                           const unsigned short *xh, const unsigned short *xl, const float *nyk, int *cand,
+                           float *key_last) {
+#define DGNN_KNN_MFMA_CASE(N)                                                                              \
+  if (nkk == N) {                                                                                          \
+    if (int rc = knn_allow_lds((const void *)k_knn_mfma<KL, N>, lds)) return rc;                           \
+    hipLaunchKernelGGL((k_knn_mfma<KL, N>), grid, dim3(256), lds, st, points, pp, nq, xh, xl, nyk, cand,   \
+                       key_last);                                                                          \
+    return DGNN_OK;                                                                                        \
+  }
+  DGNN_KNN_MFMA_CASE(2)
+  DGNN_KNN_MFMA_CASE(4)
+  DGNN_KNN_MFMA_CASE(8)
+#undef DGNN_KNN_MFMA_CASE
+  return DGNN_ERR_UNSUPPORTED;
+}
+
+static int launch_knn_rerank(int batch, int points, int pp, int dim, int k, int kl, const float *x, const float *nyk,
+                             const int *cand, float *key_last, const int *bad, int *src_ind, int *rflags, int *flags,
+                             int *qflags, hipStream_t st) {
+  const dim3 grid((unsigned)((points + 63) / 64), (unsigned)batch);
+  const long long nq = (long long)batch * points;
+  const size_t lds = ((size_t)4 * 64 * KNN_RS + (size_t)kl * 64 * 2 + 64) * sizeof(float);
+#define DGNN_KNN_RR_CASE(FCV)                                                                            \
+  if (dim <= FCV) {                                                                                      \
+    if (int rc = knn_allow_lds((const void *)k_knn_rerank<FCV>, lds)) return rc;                         \
+    hipLaunchKernelGGL((k_knn_rerank<FCV>), grid, dim3(256), lds, st, points, pp, dim, k, kl, nq, x, nyk, cand, \
+                       key_last, bad, src_ind, rflags, flags, qflags, env_int("DGNN_KNN_REDO_MAX", KNN_REDO_MAX)); \
+    DGNN_LAUNCH_CHECK();                                                                                 \
+    return DGNN_OK;                                                                                      \
+  }
+  DGNN_KNN_RR_CASE(32)
+  DGNN_KNN_RR_CASE(64)
+  DGNN_KNN_RR_CASE(128)
+#undef DGNN_KNN_RR_CASE
+  return DGNN_ERR_UNSUPPORTED;
+}
+
+static int launch_knn_redo(int batch, int points, int dim, int k, const float *x, const int *rflags, const int *qflags,
+                           const float *dk_bound, int *flags, int *src_ind, hipStream_t st) {
+  const dim3 grid((unsigned)((points + 63) / 64), (unsigned)batch);
+  if (dim <= 32)
+    hipLaunchKernelGGL((k_knn_redo<32>), grid, dim3(256), 0, st, points, dim, k, x, rflags, qflags, dk_bound, flags, src_ind);
+  else if (dim <= 64)
+    hipLaunchKernelGGL((k_knn_redo<64>), grid, dim3(256), 0, st, points, dim, k, x, rflags, qflags, dk_bound, flags, src_ind);
+  else
+    hipLaunchKernelGGL((k_knn_redo<128>), grid, dim3(256), 0, st, points, dim, k, x, rflags, qflags, dk_bound, flags, src_ind);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+template <int KMAX>
+static int knn_filtered(int batch, int points, int dim, int k, const float *x, int *src_ind, unsigned char *ws,
+                        hipStream_t st) {
+  const KnnWs w = knn_ws_layout(batch, points, dim, k);
+  unsigned short *xh = (unsigned short *)(ws + w.off_xh), *xl = (unsigned short *)(ws + w.off_xl);
+  float *nyk = (float *)(ws + w.off_nyk), *key_last = (float *)(ws + w.off_key);
+  int *cand = (int *)(ws + w.off_cand), *bad = (int *)(ws + w.off_bad), *flags = (int *)(ws + w.off_flags);
+  const long long nq = (long long)batch * points;
+  if (hipError_t e = hipMemsetAsync(bad, 0, (size_t)batch * 4, st); e != hipSuccess) return (int)e;
+  {
+    const long long threads = (long long)w.pp * (w.dimp / 8);
+    hipLaunchKernelGGL(k_knn_split, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, st,
+                       points, w.pp, dim, w.dimp, x, xh, xl, nyk, bad);
+    DGNN_LAUNCH_CHECK();
+  }
+  {
+    const dim3 grid((unsigned)((points + 127) / 128), (unsigned)batch);
+    const size_t per_wave = (size_t)((w.kl * 32 * 2 > KNN_MQ * 64 * 2) ? w.kl * 32 * 2 : KNN_MQ * 64 * 2) * 4;
+    int rc;
+    if (w.kl == 24) rc = launch_knn_mfma<24>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else if (w.kl == 32) rc = launch_knn_mfma<32>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else if (w.kl == 48) rc = launch_knn_mfma<48>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else rc = launch_knn_mfma<64>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    if (rc) return rc;
+    DGNN_LAUNCH_CHECK();
+  }
+  int *qflags = (int *)(ws + w.off_qflags), *rflags = (int *)(ws + w.off_rflags);
+  if (int rc = launch_knn_rerank(batch, points, w.pp, dim, k, w.kl, x, nyk, cand, key_last, bad, src_ind, rflags, flags,
+                                 qflags, st))
+    return rc;
+  // second stage: blocks with a few uncertified queries, query by query; then blocks with many
+  if (int rc = launch_knn_redo(batch, points, dim, k, x, rflags, qflags, key_last, flags, src_ind, st)) return rc;
+  return launch_knn<KMAX>(batch, points, dim, k, x, src_ind, st, flags);            // flagged query blocks only
 }
 
 }  // namespace
@@ -276,8 +890,19 @@ int launch_knn(int batch, int points, int dim, int k, const float *x, int *src_i
 
 using namespace dgnn;
 
+extern "C" size_t dgnn_knn_graph_workspace_bytes(int batch, int points, int dim, int k) {
+  if (batch <= 0 || points <= 0 || dim <= 0 || k <= 0 || k > points) return 0;
+  if (!knn_filter_applies(batch, points, dim, k)) return 0;
+  return knn_ws_layout(batch, points, dim, k).total;
+}
+
 extern "C" int dgnn_knn_graph(int batch, int points, int dim, int k, const float *x, int *src_ind,
                               void *stream) {
+  return dgnn_knn_graph_ws(batch, points, dim, k, x, src_ind, nullptr, 0, stream);
+}
+
+extern "C" int dgnn_knn_graph_ws(int batch, int points, int dim, int k, const float *x, int *src_ind,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
   if (batch < 0 || points < 0 || dim <= 0 || k <= 0) return DGNN_ERR_BAD_ARG;
   if (batch == 0 || points == 0) return DGNN_OK;
   if (k > points) return DGNN_ERR_BAD_ARG;          // a cloud cannot supply k distinct points
@@ -285,6 +910,17 @@ extern "C" int dgnn_knn_graph(int batch, int points, int dim, int k, const float
   if ((long long)batch * points > (1LL << 31) - 1) return DGNN_ERR_UNSUPPORTED;
   if (!x || !src_ind) return DGNN_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (workspace != nullptr && knn_filter_applies(batch, points, dim, k)) {
+    if (workspace_bytes < knn_ws_layout(batch, points, dim, k).total || ((size_t)workspace & 255) != 0)
+      return DGNN_ERR_BAD_ARG;
+    unsigned char *ws = (unsigned char *)workspace;
+    if (k <= 20) return knn_filtered<20>(batch, points, dim, k, x, src_ind, ws, st);
+    if (k <= 24) return knn_filtered<24>(batch, points, dim, k, x, src_ind, ws, st);
+    if (k <= 32) return knn_filtered<32>(batch, points, dim, k, x, src_ind, ws, st);
+    if (k <= 40) return knn_filtered<40>(batch, points, dim, k, x, src_ind, ws, st);
+    if (k <= 48) return knn_filtered<48>(batch, points, dim, k, x, src_ind, ws, st);
+    return knn_filtered<64>(batch, points, dim, k, x, src_ind, ws, st);
+  }
   if (k <= 8) return launch_knn<8>(batch, points, dim, k, x, src_ind, st);
   if (k <= 16) return launch_knn<16>(batch, points, dim, k, x, src_ind, st);
   if (k <= 20) return launch_knn<20>(batch, points, dim, k, x, src_ind, st);   // the reference's default k

@@ -748,8 +748,11 @@ Tensor knn_graph(const Tensor &x_in, int64_t k) {
   const int batch = as_int(x.size(0), "batch"), points = as_int(x.size(1), "points"), dim = as_int(x.size(2), "dim");
   c10::DeviceGuard guard(x.device());
   Tensor src_ind = new_i32({(int64_t)batch * points * k}, x);
-  check_rc(API(dgnn_knn_graph)(batch, points, dim, as_int(k, "k"), fp(x), io(src_ind), stream_of(x)),
-           "dgnn_knn_graph");
+  const size_t nb = API(dgnn_knn_graph_workspace_bytes)(batch, points, dim, as_int(k, "k"));
+  Tensor ws = workspace(nb, x);
+  check_rc(API(dgnn_knn_graph_ws)(batch, points, dim, as_int(k, "k"), fp(x), io(src_ind), nb ? ws.data_ptr() : nullptr,
+                                  nb, stream_of(x)),
+           "dgnn_knn_graph_ws");
   return src_ind;
 }
 

@@ -386,6 +386,19 @@ int dgnn_gmm_backward_sum(int nodes, int nnz, int kernels, int dim, int embed, c
 int dgnn_knn_graph(int batch, int points, int dim, int k, const float *x, int *src_ind,
                    void *stream);
 
+/* The same graph, same ids bit for bit, with a workspace: for 17 .. 128 dims and enough queries to
+ * fill the chip a coarse candidate filter runs on the matrix cores first (split-bf16 products
+ * accumulated in float32 give, per query, a list of k + slack candidates by a LOWER BOUND of the
+ * exact distance), the exact float32 chain is evaluated for those candidates only, and a query whose
+ * k-th exact distance is not strictly below the bound of everything outside its list (ties,
+ * duplicate points, non-finite input) is recomputed by the exhaustive kernel of dgnn_knn_graph.
+ * Same reference call site as dgnn_knn_graph (script/train/train_edgeconv.py:17,49-52).
+ * dgnn_knn_graph_workspace_bytes returns 0 when the filter does not apply (then the call is
+ * dgnn_knn_graph); workspace == NULL always selects the exhaustive kernel.  256-byte aligned. */
+size_t dgnn_knn_graph_workspace_bytes(int batch, int points, int dim, int k);
+int dgnn_knn_graph_ws(int batch, int points, int dim, int k, const float *x, int *src_ind,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- GAT layer steps on either side of the fused operator, one pass each -------------------
  * attn_row[n,h] = <attn_l[h,:], feat[n,h,:]>, attn_col[n,h] = <attn_r[h,:], feat[n,h,:]>.
  * Replaces the two multiply + sum chains of dgNN/layers/gatconv_layer.py:74-75 (attn_l is the

@@ -632,6 +632,69 @@ def test_edgeconv_continuous_values_and_operator(nat):
     assert np.array_equal(host(hd.grad), go)
 
 
+@pytest.mark.parametrize("f", [64, 256])
+def test_edgeconv_at_the_dgcnn_batch_size(nat, f):
+    """BASELINE configs[2] at its full size: 32 clouds x 2048 points = 65 536 points, k = 20
+    (script/train/train_edgeconv.py:49-52), first and last DGCNN width: forward values and arg-max
+    ids bit-exact against the oracle, both backward forms against the float64 oracle."""
+    m, k = 32 * 2048, 20
+    rng = np.random.default_rng(f)
+    # neighbours stay inside a point's own cloud, as the k-NN graph in front of the operator gives them
+    cloud = (np.arange(m) // 2048)[:, None]
+    src = (cloud * 2048 + rng.integers(0, 2048, (m, k))).astype(np.int32)
+    h_src = rng.standard_normal((m, f)).astype(np.float32)
+    h_dst = rng.standard_normal((m, f)).astype(np.float32)
+    go = rng.standard_normal((m, f)).astype(np.float32)
+    out, idx_f, idx_i = nat["edge"].edgeconv_forward(k, dev(src.reshape(-1)), dev(h_src), dev(h_dst), return_int_idx=True)
+    ref_out, ref_idx = oracle.edgeconv_forward(k, src.reshape(-1), h_src, h_dst)
+    assert np.array_equal(host(out), ref_out)
+    assert np.array_equal(host(idx_i), ref_idx.astype(np.int32)), "arg-max ids must be bit-exact"
+    want = oracle.edgeconv_backward_f64(go, ref_idx.astype(np.int32))
+    mass = oracle.edgeconv_backward_f64(np.abs(go), ref_idx.astype(np.int32))
+    assert_close(host(nat["edge"].edgeconv_backward(dev(go), idx_i)), want, "edgeconv bwd (atomics), full batch", mass=mass)
+    from dgnn_amd.operators import EdgeConvFuse
+    hs, hd = dev(h_src).requires_grad_(), dev(h_dst).requires_grad_()
+    EdgeConvFuse(k, dev(src.reshape(-1)), hs, hd).backward(dev(go))
+    assert_close(host(hs.grad), want, "EdgeConvFuse: grad_src, full batch", mass=mass)
+    assert np.array_equal(host(hd.grad), go)
+
+
+def test_gmm_at_the_pubmed_shape(nat):
+    """BASELINE configs[1] (MoNet on PubMed: 19 717 nodes, 108 365 edges with self loops, K = 3,
+    pseudo dim 2, 64 hidden; test/gmm_result.sh): forward, Gaussian, GaussianBp and the fused
+    backward at that size against the float64 oracle."""
+    g = rmat_graph(15, 19717, 108365, 9)
+    G = gdev(g)
+    k, d, f = 3, 2, 64
+    rng = np.random.default_rng(4)
+    node_feat = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    pseudo = rng.random((g["nnz"], d), dtype=np.float32)
+    mu = (0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    inv_sigma = (1 + 0.1 * rng.standard_normal((k, d))).astype(np.float32)
+    grad = rng.standard_normal((g["n"], k, f)).astype(np.float32)
+    gg = rng.standard_normal((g["nnz"], k)).astype(np.float32)
+    out = nat["gmm"].gmmconv(G["row_ptr"], G["col_ind"], dev(node_feat), dev(pseudo), dev(mu), dev(inv_sigma))
+    assert_close(host(out), oracle.gmmconv_f64(g["row_ptr"], g["col_ind"], node_feat, pseudo, mu, inv_sigma),
+                 "gmm forward, PubMed shape",
+                 mass=oracle.gmmconv_f64(g["row_ptr"], g["col_ind"], np.abs(node_feat), pseudo, mu, inv_sigma))
+    po, mo, so = nat["gmm"].GaussianBp(dev(pseudo), dev(mu), dev(inv_sigma), dev(gg))
+    po64, mo64, so64 = oracle.gaussian_bp_f64(pseudo, mu, inv_sigma, gg)
+    m_po, m_mo, m_so = gaussian_bp_masses(pseudo, mu, inv_sigma, np.abs(gg))
+    assert_close(host(po), po64, "GaussianBp, PubMed shape: pseudo grad", mass=m_po)
+    assert_close(host(mo), mo64, "GaussianBp, PubMed shape: mu grad", mass=m_mo)
+    assert_close(host(so), so64, "GaussianBp, PubMed shape: inv_sigma grad", mass=m_so)
+    fused = nat["gmm"].gmm_backward_fused(G["col_ptr"], G["row_ind"], G["permute"], dev(node_feat), dev(pseudo),
+                                          dev(mu), dev(inv_sigma), dev(grad))
+    assert fused is not None
+    pseudo_csc = pseudo[g["permute"]]
+    assert_close(host(fused[0]), oracle.gmmconv_f64(g["col_ptr"], g["row_ind"], grad, pseudo_csc, mu, inv_sigma),
+                 "fused gmm backward, PubMed shape: grad_node_feat",
+                 mass=oracle.gmmconv_f64(g["col_ptr"], g["row_ind"], np.abs(grad), pseudo_csc, mu, inv_sigma))
+    assert_close(host(fused[1]), oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], grad, node_feat),
+                 "fused gmm backward, PubMed shape: grad_gauss",
+                 mass=oracle.mhsddmm_f64(g["row_ptr"], g["col_ind"], np.abs(grad), np.abs(node_feat)))
+
+
 # ----------------------------------------------------------------------------- k-NN graph
 @pytest.mark.parametrize("b,p,dim,k", [
     (3, 50, 3, 5), (2, 300, 3, 20), (2, 257, 64, 20), (1, 1000, 128, 20), (2, 90, 200, 33),
@@ -689,6 +752,50 @@ def test_knn_graph_with_nan_and_inf_points_stays_in_range():
     h = dev(x.reshape(-1, 5))
     out, idx = fused_edgeconv.edgeconv_forward(k, src, h, h)     # must not fault
     assert out.shape == (210, 5)
+
+
+@pytest.mark.parametrize("b,p,dim,k,kind", [
+    (3, 300, 64, 20, "normal"), (2, 257, 17, 20, "normal"), (2, 333, 33, 9, "normal"), (1, 1000, 128, 20, "normal"),
+    (2, 200, 100, 24, "normal"), (2, 150, 70, 28, "normal"), (1, 500, 128, 40, "normal"), (1, 300, 90, 56, "normal"),
+    (1, 2048, 64, 20, "normal"), (2, 300, 64, 20, "quantised"), (2, 260, 40, 20, "duplicates"),
+    (2, 300, 64, 20, "clustered"), (2, 200, 64, 12, "nonfinite"), (2, 300, 32, 20, "huge"), (2, 300, 48, 20, "tiny"),
+    (1, 4500, 20, 5, "normal")])
+def test_knn_filtered_path_is_bit_exact(b, p, dim, k, kind, monkeypatch):
+    """The matrix-core candidate filter in front of the exact chain (csrc/knn.hip, dims 17 .. 128)
+    is forced on for small problems: ids bit-exact against the oracle's exhaustive search on
+    continuous data (the filter certifies nearly every query), on data made of exact ties and
+    duplicates (it certifies nothing: every query goes back to the exhaustive chain), on tight
+    clusters far from the origin (norms >> distances: the certificate's margin decides), on
+    non-finite points and at the ends of the float32 range."""
+    from dgnn_amd.native.knn import knn_graph
+    monkeypatch.setenv("DGNN_KNN_FILTER_MIN_WAVES", "1")
+    rng = np.random.default_rng(b * 1000 + p + dim)
+    x = rng.standard_normal((b, p, dim)).astype(np.float32)
+    if kind == "quantised":
+        x = rng.integers(-1, 2, (b, p, dim)).astype(np.float32)
+    elif kind == "duplicates":
+        x[:, p // 2:] = x[:, :p - p // 2]
+    elif kind == "clustered":
+        x = (100.0 + 0.01 * x).astype(np.float32)
+    elif kind == "nonfinite":
+        x[0, 3] = np.nan
+        x[0, 7, 5] = np.inf
+        x[1, :150] = np.inf
+    elif kind == "huge":
+        x = (x * 1e18).astype(np.float32)
+    elif kind == "tiny":
+        x = (x * 1e-20).astype(np.float32)
+    want = oracle.knn_graph(x, k)
+    got = host(knn_graph(dev(x), k))
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("DGNN_KNN_FILTER", "0")
+    assert np.array_equal(host(knn_graph(dev(x), k)), want)
+    # both forms of the second stage: every uncertified query redone on its own (however many a
+    # block has), and every block with an uncertified query handed to the exhaustive kernel
+    monkeypatch.setenv("DGNN_KNN_FILTER", "1")
+    for redo_max in ("64", "0"):
+        monkeypatch.setenv("DGNN_KNN_REDO_MAX", redo_max)
+        assert np.array_equal(host(knn_graph(dev(x), k)), want), redo_max
 
 
 def test_knn_feeds_edgeconv_like_the_reference_model():
