@@ -343,12 +343,19 @@ __global__ void k_knn_split(int points, int pp, int dim, int dimp, const float *
                                    hi[4] | (unsigned)hi[5] << 16, hi[6] | (unsigned)hi[7] << 16);
   *(uint4 *)(xl + at) = make_uint4(lo[0] | (unsigned)lo[1] << 16, lo[2] | (unsigned)lo[3] << 16,
                                    lo[4] | (unsigned)lo[5] << 16, lo[6] | (unsigned)lo[7] << 16);
+  // |x|^2: every thread squares its 8 dims, the row's threads (4, 8 or 16 consecutive lanes) add up
+  float part = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int f = g * 8 + e;
+    const float v = (j < points && f < dim) ? row[f] : 0.f;
+    part = fmaf(v, v, part);
+  }
+  for (int off = 1; off < groups; off <<= 1) part += __shfl_xor(part, off, 64);
   if (g == 0) {
     float ny = __builtin_inff();
     if (j < points) {
-      ny = 0.f;
-      for (int f = 0; f < dim; ++f) ny = fmaf(row[f], row[f], ny);
-      ny *= (1.f - KNN_C);
+      ny = part * (1.f - KNN_C);
       if (!(ny < __builtin_inff())) cloud_bad[b] = 1;      // inf or NaN: the filter certifies nothing here
     }
     nyk[(size_t)b * pp + j] = ny;
@@ -487,6 +494,151 @@ void k_knn_mfma(int points, int pp, long long nq, const unsigned short *__restri
 #pragma unroll
       for (int t = 0; t < KL; ++t) cand[(size_t)t * nq + gq] = best.id[t];
       key_last[gq] = best.d[KL - 1];
+    }
+  }
+}
+
+// The same pass for clouds of at most 2048 points (the DGCNN sizes), with the sorted list as ONE
+// 32-bit word per entry: the lower bound LB = max(0, key + (1 - c) nx) >= 0 orders like its bit
+// pattern, its low 11 mantissa bits are replaced by the candidate's index in the cloud (LB rounded
+// DOWN by at most 2^-12 LB: still a lower bound), and an insertion is one v_med3_u32 per slot
+// instead of five instructions on (key, id) pairs -- the insertion is what this kernel spends its
+// time on.  Words at or above the bits of +inf mean "no entry".
+constexpr unsigned KNN_PK_IDX = 0x7ffu;
+constexpr unsigned KNN_PK_INF = 0x7f800000u;
+template <int KL>
+struct TopKPacked {
+  unsigned v[KL];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < KL; ++t) v[t] = 0xffffffffu;
+  }
+  __device__ __forceinline__ void push(unsigned x) {
+    if (x < v[KL - 1]) {
+      unsigned prev = 0u;
+#pragma unroll
+      for (int t = 0; t < KL; ++t) {       // sorted, prev <= old: the median of (prev, x, old)
+        const unsigned old = v[t];
+        v[t] = min(max(prev, x), old);
+        prev = old;
+      }
+    }
+  }
+};
+
+// (Measured and dropped: the block's four waves sharing every candidate tile through a
+// double-buffered LDS stage instead of each wave loading its fragments from L2 -- 204 -> 226 us at
+// 64 dims: the barriers cost more than the 4x lower L2 traffic saves.)
+template <int KL, int NKK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_knn_mfma_packed(int points, int pp, long long nq, const unsigned short *__restrict__ xh,
+                       const unsigned short *__restrict__ xl, const float *__restrict__ nyk,
+                       int *__restrict__ cand, float *__restrict__ key_last) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int DIMP = NKK * 16;
+  constexpr int PER_WAVE = (KL * 32 > KNN_MQ * 64) ? KL * 32 : KNN_MQ * 64;        // words
+  const int wave = wave_in_block(), lane = lane_id();
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int q0 = uniform_i32((blockIdx.x * 4 + wave) * 32);
+  if (q0 >= points) return;                                  // no block-wide barrier below
+  unsigned *qv = (unsigned *)lds + (size_t)wave * PER_WAVE;  // [KNN_MQ][64] queued words
+  const size_t base = (size_t)b * pp;
+  const bf16x8 *gh = (const bf16x8 *)xh, *gl = (const bf16x8 *)xl;
+  auto frag = [&](size_t row, int kk) { return row * (DIMP / 8) + 2 * kk + h; };
+  bf16x8 bh[NKK], bl[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    bh[kk] = gh[frag(base + q0 + r, kk)];
+    bl[kk] = gl[frag(base + q0 + r, kk)];
+  }
+  const float nxk = nyk[base + q0 + r];                      // (1 - c) |x|^2 of this lane's query
+  TopKPacked<KL> best;
+  best.init();
+  int queued = 0;
+  unsigned thr = KNN_PK_INF;                                 // +inf and NaN bounds never enter
+  auto flush = [&]() {
+    // the next queued word is read while this one is inserted
+    unsigned nxt = queued > 0 ? qv[lane] : 0xffffffffu;
+    for (int t = 0; t < KNN_MQ; ++t) {
+      if (!__any(t < queued)) break;
+      const unsigned cur = nxt;
+      nxt = (t + 1 < queued) ? qv[(t + 1) * 64 + lane] : 0xffffffffu;
+      best.push(cur);
+    }
+    queued = 0;
+  };
+  auto load = [&](bf16x8 (&ah)[NKK], bf16x8 (&al)[NKK], int j0) {
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      ah[kk] = gh[frag(base + j0 + r, kk)];
+      al[kk] = gl[frag(base + j0 + r, kk)];
+    }
+  };
+  // One fragment set: the loads of the NEXT tile are issued right behind this tile's MFMAs (which
+  // have read their operands by then) and land while the selection below runs.
+  bf16x8 ah[NKK], al[NKK];
+  auto tile = [&](int j0, int jnext) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bh[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bl[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk], bh[kk], acc, 0, 0, 0);
+    }
+    load(ah, al, jnext);
+    if (__any(queued > KNN_MQ - 17)) {
+      flush();
+      // The two lanes of a query share their bound.  The KL-th smallest word of both lists
+      // together is at most max(A[s-1], B[KL-s-1]) for every split s; s = 0, KL / 2 and KL (the
+      // lists are statistically alike, so the middle split is nearly the exact value; all KL + 1
+      // splits cost 24 cross-half moves per flush and gained nothing measurable).
+      const unsigned b_last = __shfl_xor(best.v[KL - 1], 32, 64);
+      const unsigned b_mid = __shfl_xor(best.v[KL / 2 - 1], 32, 64);
+      const unsigned u = min(min(b_last, best.v[KL - 1]), max(best.v[KL - KL / 2 - 1], b_mid));
+      thr = min(u, KNN_PK_INF);
+    }
+    // every word is written to the lane's next queue slot; the slot only counts if it passes
+    // (no exec-mask work per candidate); a tile adds at most 16, the flush above left room
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 n4 = *(const float4 *)(nyk + base + j0 + 8 * g + 4 * h);
+      const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lb = fmaxf(fmaf(-2.f, acc[4 * g + e], nn[e]) + nxk, 0.f);
+        const unsigned w = (__float_as_uint(lb) & ~KNN_PK_IDX) | (unsigned)(j0 + 8 * g + 4 * h + e);
+        qv[queued * 64 + lane] = w;
+        queued += (w < thr) ? 1 : 0;
+      }
+    }
+  };
+  // (Measured without effect: waves of a cloud starting at different tiles so that they do not ask
+  // the same L2 lines at the same time; a second fragment set loaded a whole tile ahead.  What grows
+  // with the dimension is the fragment traffic through each CU's vector memory pipe: 16 KB per wave
+  // and tile at 128 dims.)
+  load(ah, al, 0);
+  for (int j0 = 0; j0 < pp; j0 += 32) tile(j0, j0 + 32 < pp ? j0 + 32 : 0);
+  flush();
+  wave_lds_sync();
+  unsigned *mv = qv;                                         // [KL][32], over the (empty) queue
+  if (h == 1) {
+#pragma unroll
+    for (int t = 0; t < KL; ++t) mv[t * 32 + r] = best.v[t];
+  }
+  wave_lds_sync();
+  if (h == 0) {
+    for (int t = 0; t < KL; ++t) best.push(mv[t * 32 + r]);
+    if (q0 + r < points) {
+      const long long gq = (long long)b * points + q0 + r;
+#pragma unroll
+      for (int t = 0; t < KL; ++t)
+        cand[(size_t)t * nq + gq] = best.v[t] < KNN_PK_INF ? (int)(best.v[t] & KNN_PK_IDX) : -1;
+      // k_knn_rerank adds (1 - c) nx back: hand it the bound in the unpacked kernel's form
+      key_last[gq] = best.v[KL - 1] < KNN_PK_INF ? __uint_as_float(best.v[KL - 1] & ~KNN_PK_IDX) - nxk
+                                                 : __builtin_inff();
     }
   }
 }
@@ -679,7 +831,7 @@ void k_knn_rerank(int points, int pp, int dim, int k, int kl, long long nq, cons
 }
 
 // The few queries the filter could not certify, one BLOCK pass per query: the list's k-th exact
-// distance bounds every true neighbour, so the 256 lanes evaluate the exact chain for all of the
+// distance bounds every true neighbour, so the block's 256 lanes evaluate the exact chain for all of the
 // cloud's candidates, keep those within the bound (k plus a handful), and rank them by (distance,
 // id).  More survivors than the buffer holds (a cloud of exact ties) hands the block to k_knn.
 constexpr int KNN_REDO_CAP = 1024;
@@ -693,6 +845,7 @@ void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const i
   __shared__ int cnt;
   const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (redo_flags[blk] == 0) return;
+  constexpr int NT = 256;
   const int tid = threadIdx.x, b = blockIdx.y;
   const float *xc = x + (size_t)b * points * dim;
   const bool vec4 = (dim & 3) == 0 && ((size_t)x & 15) == 0;
@@ -707,7 +860,7 @@ void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const i
     float xi[FC];
 #pragma unroll
     for (int f = 0; f < FC; ++f) xi[f] = (f < dim) ? xc[(size_t)i * dim + f] : 0.f;
-    for (int c = tid; c < points; c += 256) {
+    for (int c = tid; c < points; c += NT) {
       const float *cj = xc + (size_t)c * dim;
       float acc = 0.f;
       if (vec4) {
@@ -744,7 +897,7 @@ void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const i
     }
     int *o = src_ind + gq * k;
     const int gbase = b * points;
-    for (int t = tid; t < m; t += 256) {
+    for (int t = tid; t < m; t += NT) {
       const float dt = sd[t];
       const int jt = sj[t];
       int rank = 0;
@@ -755,7 +908,7 @@ void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const i
       }
       if (rank < k) o[rank] = gbase + jt;
     }
-    for (int t = m + tid; t < k; t += 256) o[t] = gbase + i;     // fewer finite candidates than k
+    for (int t = m + tid; t < k; t += NT) o[t] = gbase + i;     // fewer finite candidates than k
     __syncthreads();
   }
 }
@@ -796,6 +949,25 @@ static bool knn_filter_applies(int batch, int points, int dim, int k) {
   if (knn_filter_list(k) > 32 && dim <= 64) return false;    // long lists run one wave per SIMD: the chain must dominate
   if (points < 2 * knn_filter_list(k)) return false;
   return (long long)batch * ((points + 31) / 32) >= env_int("DGNN_KNN_FILTER_MIN_WAVES", 512);
+}
+
+template <int KL>
+static int launch_knn_mfma_packed(int nkk, dim3 grid, hipStream_t st, int points, int pp, long long nq,
+                                  const unsigned short *xh, const unsigned short *xl, const float *nyk, int *cand,
+                                  float *key_last) {
+  const size_t queue = (size_t)4 * ((KL * 32 > KNN_MQ * 64) ? KL * 32 : KNN_MQ * 64) * sizeof(unsigned);
+#define DGNN_KNN_MFMA_CASE(N)                                                                              \
+  if (nkk == N) {                                                                                          \
+    const size_t lds = queue;                                                                              \
+    hipLaunchKernelGGL((k_knn_mfma_packed<KL, N>), grid, dim3(256), lds, st, points, pp, nq, xh, xl, nyk,  \
+                       cand, key_last);                                                                    \
+    return DGNN_OK;                                                                                        \
+  }
+  DGNN_KNN_MFMA_CASE(2)
+  DGNN_KNN_MFMA_CASE(4)
+  DGNN_KNN_MFMA_CASE(8)
+#undef DGNN_KNN_MFMA_CASE
+  return DGNN_ERR_UNSUPPORTED;
 }
 
 template <int KL>
@@ -869,7 +1041,10 @@ static int knn_filtered(int batch, int points, int dim, int k, const float *x, i
     const dim3 grid((unsigned)((points + 127) / 128), (unsigned)batch);
     const size_t per_wave = (size_t)((w.kl * 32 * 2 > KNN_MQ * 64 * 2) ? w.kl * 32 * 2 : KNN_MQ * 64 * 2) * 4;
     int rc;
-    if (w.kl == 24) rc = launch_knn_mfma<24>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    const bool packed = w.pp <= 2048 && w.kl <= 32 && env_int("DGNN_KNN_PACKED", 1) != 0;
+    if (packed && w.kl == 24) rc = launch_knn_mfma_packed<24>(w.dimp / 16, grid, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else if (packed) rc = launch_knn_mfma_packed<32>(w.dimp / 16, grid, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else if (w.kl == 24) rc = launch_knn_mfma<24>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
     else if (w.kl == 32) rc = launch_knn_mfma<32>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
     else if (w.kl == 48) rc = launch_knn_mfma<48>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
     else rc = launch_knn_mfma<64>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);

@@ -796,6 +796,10 @@ def test_knn_filtered_path_is_bit_exact(b, p, dim, k, kind, monkeypatch):
     for redo_max in ("64", "0"):
         monkeypatch.setenv("DGNN_KNN_REDO_MAX", redo_max)
         assert np.array_equal(host(knn_graph(dev(x), k)), want), redo_max
+    # clouds of at most 2048 points keep (bound, index) packed in one word per list entry; the
+    # (key, id) form that larger clouds use gives the same ids
+    monkeypatch.setenv("DGNN_KNN_PACKED", "0")
+    assert np.array_equal(host(knn_graph(dev(x), k)), want)
 
 
 def test_knn_feeds_edgeconv_like_the_reference_model():
