@@ -29,19 +29,30 @@ __global__ void k_ptr_from_sorted(int n, int nnz, const int *__restrict__ sorted
     ptr[c] = lower_bound_i32(sorted_keys, nnz, (int)c);
 }
 
-// row_ind[i] = row that owns CSR position permute[i]: last r with row_ptr[r] <= pos
-__global__ void k_rows_of_positions(int m, int nnz, const int *__restrict__ row_ptr,
-                                    const int *__restrict__ permute, int *__restrict__ row_ind) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int pos = permute[i];
-    int lo = 0, hi = m;  // invariant: row_ptr[lo] <= pos < row_ptr[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (row_ptr[mid] <= pos) lo = mid; else hi = mid;
-    }
-    row_ind[i] = lo;
+// rows_csr[p] = row that owns CSR position p.  One wave per 64 consecutive rows: the lanes load the
+// 65 row bounds once and then fill row after row with coalesced stores (a hub row of 10^5 entries
+// is 1600 store instructions of one wave; short rows cost one instruction each).
+__global__ __launch_bounds__(DGNN_BLOCK) void k_expand_rows(int m, const int *__restrict__ row_ptr,
+                                                            int *__restrict__ rows_csr) {
+  const int lane = lane_id();
+  const long long r0 = (long long)(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) * DGNN_WAVE;
+  if (r0 >= m) return;
+  const int lo = row_ptr[min((long long)m, r0 + lane)];
+  const int hi = row_ptr[min((long long)m, r0 + lane + 1)];
+  const int nrows = (int)min((long long)DGNN_WAVE, m - r0);
+  for (int rr = 0; rr < nrows; ++rr) {
+    const int s = __shfl(lo, rr, DGNN_WAVE), e = __shfl(hi, rr, DGNN_WAVE);
+    for (int p = s + lane; p < e; p += DGNN_WAVE) rows_csr[p] = (int)(r0 + rr);
   }
+}
+
+// row_ind[i] = rows_csr[permute[i]]  (replaces a 22-step binary search over row_ptr per entry:
+// 3.9 ms and 14.7 GB of L2 traffic for 62 M entries, profiles/r2d_*_products.csv)
+__global__ void k_gather_rows(int nnz, const int *__restrict__ permute, const int *__restrict__ rows_csr,
+                              int *__restrict__ row_ind) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz;
+       i += (long long)gridDim.x * blockDim.x)
+    row_ind[i] = rows_csr[permute[i]];
 }
 
 static inline int grid_1d(long long total, int block) {
@@ -74,7 +85,10 @@ size_t dgnn_csr2csc_workspace_bytes(int m, int n, int nnz) {
   if (nnz <= 0 || n <= 0) return 0;
   size_t temp = 0;
   if (sort_temp_bytes(nnz, key_bits(n), &temp) != hipSuccess) return 0;
-  return align_up(sizeof(int) * (size_t)nnz, 256) + align_up(temp, 256);
+  // sorted keys; then the sort's scratch and, after the sort, the row of every CSR position share a region
+  const size_t after = align_up(temp, 256) > align_up(sizeof(int) * (size_t)nnz, 256) ? align_up(temp, 256)
+                                                                                       : align_up(sizeof(int) * (size_t)nnz, 256);
+  return align_up(sizeof(int) * (size_t)nnz, 256) + after;
 }
 
 int dgnn_csr2csc(int m, int n, int nnz, const int *row_ptr, const int *col_ind, int *col_ptr,
@@ -93,7 +107,7 @@ int dgnn_csr2csc(int m, int n, int nnz, const int *row_ptr, const int *col_ind, 
   hipError_t e = sort_temp_bytes(nnz, bits, &temp);
   if (e != hipSuccess) return (int)e;
   const size_t keys_bytes = align_up(sizeof(int) * (size_t)nnz, 256);
-  if (!workspace || workspace_bytes < keys_bytes + align_up(temp, 256)) return DGNN_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < dgnn_csr2csc_workspace_bytes(m, n, nnz)) return DGNN_ERR_WORKSPACE;
   int *sorted_keys = (int *)workspace;
   void *sort_tmp = (char *)workspace + keys_bytes;
   // stable sort of (column, CSR position): positions of one column stay ascending, i.e. rows ascending
@@ -103,8 +117,12 @@ int dgnn_csr2csc(int m, int n, int nnz, const int *row_ptr, const int *col_ind, 
   hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_1d((long long)n + 1, 256)), dim3(256), 0, st, n,
                      nnz, (const int *)sorted_keys, col_ptr);
   DGNN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_rows_of_positions, dim3(grid_1d(nnz, 256)), dim3(256), 0, st, m, nnz,
-                     row_ptr, (const int *)permute, row_ind);
+  int *rows_csr = (int *)sort_tmp;          // the sort is done (stream order): its scratch is free
+  hipLaunchKernelGGL(k_expand_rows, dim3(blocks_for_waves(((long long)m + DGNN_WAVE - 1) / DGNN_WAVE)),
+                     dim3(DGNN_BLOCK), 0, st, m, row_ptr, rows_csr);
+  DGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_1d(nnz, 256)), dim3(256), 0, st, nnz, (const int *)permute,
+                     (const int *)rows_csr, row_ind);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

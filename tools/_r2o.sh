@@ -1,14 +1,7 @@
 set -e
 mkdir -p gpurun_out/r2p
-timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_examples.py -m gpu -x -q --timeout 200 --timeout-method thread -k "knn or edgeconv or dgcnn" > gpurun_out/r2p/knn_tests.log 2>&1 || { tail -40 gpurun_out/r2p/knn_tests.log; exit 1; }
-tail -3 gpurun_out/r2p/knn_tests.log
-timeout -k 10 300 python tools/knn_bench.py > gpurun_out/r2p/knn_bench.log 2>&1
-cat gpurun_out/r2p/knn_bench.log
-cd examples
-rm -f ../gpurun_out/r2p/dgcnn.csv
-timeout -k 10 300 python3 train_edgeconv.py --batch-size 32 --num-points 2048 --k 20 --n-epochs 20 --output ../gpurun_out/r2p/dgcnn.csv > ../gpurun_out/r2p/dgcnn.log 2>&1
-timeout -k 10 300 python3 train_edgeconv.py --batch-size 64 --num-points 1024 --k 40 --n-epochs 20 --output ../gpurun_out/r2p/dgcnn.csv >> ../gpurun_out/r2p/dgcnn.log 2>&1
-cat ../gpurun_out/r2p/dgcnn.csv
-cd ..
-bash tools/profile.sh r2e edgeconv tools/profile_ops.py edgeconv > gpurun_out/r2p/prof_edgeconv.log 2>&1
-echo profiled
+timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q --timeout 200 --timeout-method thread -k "csr2csc or index or transpose or convert or graph" > gpurun_out/r2p/idx_tests.log 2>&1 || { tail -40 gpurun_out/r2p/idx_tests.log; exit 1; }
+tail -2 gpurun_out/r2p/idx_tests.log
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2p/csr2csc -- python3 $GRAFT_REPO_ROOT/tools/csr2csc_bench.py products > $GRAFT_REPO_ROOT/gpurun_out/r2p/csr2csc.log 2>&1
+grep "^{" $GRAFT_REPO_ROOT/gpurun_out/r2p/csr2csc.log
