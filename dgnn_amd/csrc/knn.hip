@@ -946,7 +946,10 @@ static KnnWs knn_ws_layout(int batch, int points, int dim, int k) {
 static bool knn_filter_applies(int batch, int points, int dim, int k) {
   if (env_int("DGNN_KNN_FILTER", 1) == 0) return false;
   if (dim <= 16 || dim > 128 || knn_filter_list(k) == 0) return false;
-  if (knn_filter_list(k) > 32 && dim <= 64) return false;    // long lists run one wave per SIMD: the chain must dominate
+  // long lists as (key, id) pairs run one wave per SIMD: there the chain must dominate; packed words
+  // (clouds of at most 2048 points, lists up to 48) keep two
+  const bool packed_ok = points <= 2048 && knn_filter_list(k) <= 48 && env_int("DGNN_KNN_PACKED", 1) != 0;
+  if (knn_filter_list(k) > 32 && dim <= 64 && !packed_ok) return false;
   if (points < 2 * knn_filter_list(k)) return false;
   return (long long)batch * ((points + 31) / 32) >= env_int("DGNN_KNN_FILTER_MIN_WAVES", 512);
 }
@@ -1041,9 +1044,10 @@ static int knn_filtered(int batch, int points, int dim, int k, const float *x, i
     const dim3 grid((unsigned)((points + 127) / 128), (unsigned)batch);
     const size_t per_wave = (size_t)((w.kl * 32 * 2 > KNN_MQ * 64 * 2) ? w.kl * 32 * 2 : KNN_MQ * 64 * 2) * 4;
     int rc;
-    const bool packed = w.pp <= 2048 && w.kl <= 32 && env_int("DGNN_KNN_PACKED", 1) != 0;
+    const bool packed = w.pp <= 2048 && w.kl <= 48 && env_int("DGNN_KNN_PACKED", 1) != 0;
     if (packed && w.kl == 24) rc = launch_knn_mfma_packed<24>(w.dimp / 16, grid, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
-    else if (packed) rc = launch_knn_mfma_packed<32>(w.dimp / 16, grid, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else if (packed && w.kl == 32) rc = launch_knn_mfma_packed<32>(w.dimp / 16, grid, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
+    else if (packed) rc = launch_knn_mfma_packed<48>(w.dimp / 16, grid, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
     else if (w.kl == 24) rc = launch_knn_mfma<24>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
     else if (w.kl == 32) rc = launch_knn_mfma<32>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);
     else if (w.kl == 48) rc = launch_knn_mfma<48>(w.dimp / 16, grid, 4 * per_wave, st, points, w.pp, nq, xh, xl, nyk, cand, key_last);

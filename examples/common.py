@@ -31,7 +31,8 @@ def synthetic_citation(name, device, seed=0):
     gen.manual_seed(seed)
     if name == "products":
         import bench                               # skewed R-MAT graph, self loops included
-        g = bench.build_graph("products", device, seed)
+        # node ids relabelled at load time (dgnn_amd.graph.relabel_nodes), as bench.py does
+        g = bench.build_graph("products", device, seed, labels="scrambled")
         graph = tuple(g[k] for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute"))
     else:
         src = torch.randint(0, n, (e,), device=device, generator=gen)
