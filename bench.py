@@ -403,6 +403,14 @@ def main():
                 "fwd_kernel_GBps": round(ab["fwd"] / (kf * 1e-3) / 1e9, 1) if kf > 0 else None,
                 "bwd_kernel_GBps": round(ab["bwd_csc"] / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
                 "survey_3gather_model_GBps": round(ab["survey_total"] / (ms_per_step * 1e-3) / 1e9, 1)}
+        table_bytes = n * H * F * 4
+        if table_bytes <= 256 << 20:
+            # the gathered table fits the 256 MiB Infinity Cache: the bytes counted are served by it,
+            # not by HBM, so the HBM peak is not the bound (MI355X_MICROARCH.md, gather table:
+            # uniformly random rows of a 151 MB table 7.4-7.9 TB/s, of a 38 MB table 8.6 TB/s)
+            roof["note"] = (f"feature table {table_bytes / 1e6:.0f} MB is Infinity-Cache resident: frac is against the HBM "
+                            "peak although the rows come from the cache (guide: 7.4-8.6 TB/s for random rows of "
+                            "cache-resident tables); frac > 1 is expected here")
 
     if roof is None and (use_pg or args.force_dist or args.simulate_rank):
         # partitioned run: the same two kernels on this rank's blocks (forward on n_loc rows x
