@@ -849,44 +849,74 @@ void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const i
   const int tid = threadIdx.x, b = blockIdx.y;
   const float *xc = x + (size_t)b * points * dim;
   const bool vec4 = (dim & 3) == 0 && ((size_t)x & 15) == 0;
-  for (int q = 0; q < 64; ++q) {
+  // the block's 64 flags in one load (one dependent load per query cost 0.5 us each: most of this
+  // kernel's time when a handful of queries is flagged)
+  __shared__ unsigned long long flagged;
+  if (tid < 64) {
+    const int i = blockIdx.x * 64 + tid;
+    const unsigned long long m = __ballot(i < points && query_flags[(size_t)b * points + min(i, points - 1)] != 0);
+    if (tid == 0) flagged = m;
+  }
+  __syncthreads();
+  unsigned long long todo = flagged;
+  while (todo != 0) {
+    const int q = __builtin_ctzll(todo);
+    todo &= todo - 1;
     const int i = blockIdx.x * 64 + q;
-    if (i >= points) break;
     const size_t gq = (size_t)b * points + i;
-    if (uniform_i32(query_flags[gq]) == 0) continue;
     if (tid == 0) cnt = 0;
     __syncthreads();
     const float dk = dk_bound[gq];
     float xi[FC];
 #pragma unroll
     for (int f = 0; f < FC; ++f) xi[f] = (f < dim) ? xc[(size_t)i * dim + f] : 0.f;
-    for (int c = tid; c < points; c += NT) {
-      const float *cj = xc + (size_t)c * dim;
-      float acc = 0.f;
+    // two candidates per trip, their row loads in flight together (the pass is latency-bound)
+    for (int c = tid; c < points; c += 2 * NT) {
+      const int c2 = c + NT;
+      const bool two = c2 < points;
+      const float *cj = xc + (size_t)c * dim, *cj2 = xc + (size_t)(two ? c2 : c) * dim;
+      float acc = 0.f, acc2 = 0.f;
       if (vec4) {
+        float4 v[FC / 4], v2[FC / 4];
 #pragma unroll
         for (int f4 = 0; f4 < FC / 4; ++f4) {
           if (4 * f4 < dim) {
-            const float4 v = *(const float4 *)(cj + 4 * f4);
+            v[f4] = *(const float4 *)(cj + 4 * f4);
+            v2[f4] = *(const float4 *)(cj2 + 4 * f4);
+          }
+        }
+#pragma unroll
+        for (int f4 = 0; f4 < FC / 4; ++f4) {
+          if (4 * f4 < dim) {
             float u;
-            u = xi[4 * f4 + 0] - v.x; acc = fmaf(u, u, acc);
-            u = xi[4 * f4 + 1] - v.y; acc = fmaf(u, u, acc);
-            u = xi[4 * f4 + 2] - v.z; acc = fmaf(u, u, acc);
-            u = xi[4 * f4 + 3] - v.w; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 0] - v[f4].x; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 1] - v[f4].y; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 2] - v[f4].z; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 3] - v[f4].w; acc = fmaf(u, u, acc);
+            u = xi[4 * f4 + 0] - v2[f4].x; acc2 = fmaf(u, u, acc2);
+            u = xi[4 * f4 + 1] - v2[f4].y; acc2 = fmaf(u, u, acc2);
+            u = xi[4 * f4 + 2] - v2[f4].z; acc2 = fmaf(u, u, acc2);
+            u = xi[4 * f4 + 3] - v2[f4].w; acc2 = fmaf(u, u, acc2);
           }
         }
       } else {
 #pragma unroll
         for (int f = 0; f < FC; ++f) {
           if (f < dim) {
-            const float u = xi[f] - cj[f];
+            float u = xi[f] - cj[f];
             acc = fmaf(u, u, acc);
+            u = xi[f] - cj2[f];
+            acc2 = fmaf(u, u, acc2);
           }
         }
       }
       if (acc <= dk && acc < __builtin_inff()) {              // NaN / inf: never a neighbour
         const int slot = atomicAdd(&cnt, 1);
         if (slot < KNN_REDO_CAP) { sd[slot] = acc; sj[slot] = c; }
+      }
+      if (two && acc2 <= dk && acc2 < __builtin_inff()) {
+        const int slot = atomicAdd(&cnt, 1);
+        if (slot < KNN_REDO_CAP) { sd[slot] = acc2; sj[slot] = c2; }
       }
     }
     __syncthreads();
