@@ -100,6 +100,7 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   P.steady = (vec4 && P.rowv < DGNN_WAVE && env_int("DGNN_FWD_STEADY", 1) != 0) ? 1 : 0;
   // rows of at most 32 float4 slots: several edges per load step (DGNN_FWD_PACK=0: A/B runs)
   P.pack_s = (P.steady && env_int("DGNN_FWD_PACK", 1) != 0) ? fast_pack_lanes(P.rowv, vec4) : 0;
+  P.batch_rows = env_int("DGNN_FWD_BATCH4", 1);
   {
     long long g = ((long long)P.m + 255) / 256;
     if (g > 8192) g = 8192;

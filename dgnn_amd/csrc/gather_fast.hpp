@@ -46,6 +46,7 @@ struct GatherParams {
   int sum_heads;                     // != 0: out is [m,F] = the sum over the H heads / kernels (GMMConv layer:
                                      // gmmconv_layer.py:58 `.sum(1)`), folded into the store; rows of <= 64 float4 slots
   int steady;                        // narrow rows: unguarded steady-state gather loop (phase C)
+  int batch_rows;                    // != 0: the softmax phase takes up to four short rows per pass
   int pack_s;                        // > 0: lanes per row of the PACKED gather (rows of <= 32 float4 slots:
                                      // 64 / pack_s edges of a row per load instruction), see phase C
   float attn_drop, slope;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   // along the way (one add per step); under dropout the staged weight is masked, so the unmasked
   // sum is reduced here (one more wave reduction per head and row)
   const bool an_in_b = NEG && (P.edge_mask != nullptr || P.rng.on);
+  const bool batch4 = P.batch_rows != 0;
   int nflush = 0;
   {
     int r = uniform_i32(P.task_row0[t]);
@@ -322,6 +324,124 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       const int re = uniform_i32(P.row_ptr[r + 1]);
 #endif
       const int a = max(rs, e0) - e0, b = min(re, e1) - e0;
+#if DGNN_FWD_ROWCACHE
+      // ---- up to four SHORT rows in one pass (rows of at most 16 edges, each whole inside the
+      // group): row q sits in DPP row q (lanes 16q .. 16q+15), so max and sum are the 16-lane DPP
+      // reductions alone, four rows at a time.  On the products shape 82 % of the rows have at most
+      // 16 edges and a pass per row made the softmax phase 40 % of a narrow forward's instructions.
+      // Same lanes, same reduction tree inside a row as the one-row pass: identical bits.
+      if constexpr (MODE == MODE_GAT && HT > 0) {
+        int nb = 0;                       // rows r .. r+nb-1 qualify
+        int ends[4] = {re, re, re, re};
+        if (batch4 && rs >= e0 && rk + 3 < DGNN_WAVE && r + 3 < P.m) {
+          int prev = rs;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int eq = bcast_i32(rp_c, rk + q);
+            const bool ok = nb == q && eq > prev && eq - prev <= 16 && eq <= e1;
+            if (ok) { ends[q] = eq; nb = q + 1; prev = eq; }
+          }
+        }
+        if (nb >= 2) {
+          const int qd = lane >> 4, li = lane & 15;
+          const int rstart = qd == 0 ? rs : (qd == 1 ? ends[0] : (qd == 2 ? ends[1] : ends[2]));
+          const int rend = qd == 0 ? ends[0] : (qd == 1 ? ends[1] : (qd == 2 ? ends[2] : ends[3]));
+          const bool mine = qd < nb;
+          const int p = rstart - e0 + li;
+          const bool live = mine && (e0 + p) < rend;
+          const int rq = r + (mine ? qd : 0);
+          float arow[HTA], e[HTA], mx[HTA], pe[HTA], sm[HTA];
+          ld_heads<HTA>(arow, P.attn_row + (size_t)rq * HTA);
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) e[h] = DGNN_NEG_INIT;
+          if (live) {
+            float c[HTA];
+            ld_heads<HTA>(c, sc + (size_t)p * HTA);
+#pragma unroll
+            for (int h = 0; h < HTA; ++h) e[h] = leaky_relu(arow[h] + c[h], P.slope);
+          }
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) mx[h] = row16_reduce(e[h], OpMax());
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) pe[h] = live ? expf(e[h] - mx[h]) : 0.f;
+#pragma unroll
+          for (int h = 0; h < HTA; ++h) sm[h] = row16_reduce(pe[h], OpSum());
+          float an[HTA];
+          if constexpr (NEG) {
+            if (an_in_b) {
+#pragma unroll
+              for (int h = 0; h < HTA; ++h)
+                an[h] = row16_reduce((live && e[h] < 0.f) ? pe[h] : 0.f, OpSum()) / sm[h];
+            }
+          }
+          if (live) {
+            float w[HTA];
+#pragma unroll
+            for (int h = 0; h < HTA; ++h) w[h] = pe[h] / sm[h];                                // :102
+            if (P.edge_mask != nullptr || P.rng.on) {
+              float mk[HTA];
+              if (P.rng.on) {
+#pragma unroll
+                for (int h = 0; h < HTA; ++h) mk[h] = drop_uniform(P.rng, (unsigned long long)(e0 + p) * HTA + h);
+              } else {
+                ld_heads<HTA>(mk, P.edge_mask + (size_t)(e0 + p) * HTA);
+              }
+#pragma unroll
+              for (int h = 0; h < HTA; ++h) {
+                if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
+                w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
+              }
+            }
+            if constexpr (NEG) {
+#pragma unroll
+              for (int h = 0; h < HTA; ++h)
+                if (e[h] < 0.f) w[h] = -w[h];
+            }
+            st_heads<HTA>(sc + (size_t)p * HTA, w);
+            if (e0 + p == rend - 1) cidx[p] |= DGNN_ROWEND;
+          }
+          if (mine && li == 0) {
+            if (P.edge_max != nullptr) {
+              st_heads<HTA>(P.edge_max + (size_t)rq * HTA, mx);
+              st_heads<HTA>(P.edge_sum + (size_t)rq * HTA, sm);
+            }
+            if constexpr (NEG) {
+              if (an_in_b) st_heads<HTA>(P.a_neg + (size_t)rq * HTA, an);
+            }
+            dq[nflush + qd] = rq;
+          }
+          if constexpr (STEADY) {
+            if (packed) {
+              const int G = DGNN_WAVE / P.pack_s;
+              int off = nsteps, myoff = nsteps, myns = 0;
+              int prev = rs;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if (q < nb) {
+                  const int ns = (ends[q] - prev + G - 1) / G;
+                  if (q == qd) { myoff = off; myns = ns; }
+                  off += ns;
+                  prev = ends[q];
+                }
+              }
+              if (mine && li < myns) {
+                const int p0 = rstart - e0 + li * G;
+                steps[myoff + li] = (unsigned short)((unsigned)p0 | ((unsigned)(min(G, rend - e0 - p0) - 1) << 10) |
+                                                     (li == myns - 1 ? DGNN_PACK_END : 0u));
+              }
+              nsteps = off;
+            }
+          }
+          nflush += nb;
+          const int last_end = nb == 2 ? ends[1] : (nb == 3 ? ends[2] : ends[3]);
+          r += nb - 1;
+          if (last_end >= e1 || r + 1 >= P.m) break;
+          rs = last_end;
+          ++r;
+          continue;
+        }
+      }
+#endif
       if (b > a) {
         const bool whole = (rs >= e0) && (re <= e1);
         const int slot = (rs < e0) ? 2 * t : 2 * t + 1;
