@@ -206,4 +206,4 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for w in a.which:
         {"edgeconv": edgeconv, "gmm": gmm_pubmed, "reddit": reddit, "knn": knn, "layer": layer, "shapes": shapes,
-         "odd": odd_widths}[w]()
+         "shapes_reddit": lambda: shapes("reddit"), "odd": odd_widths}[w]()
