@@ -120,6 +120,13 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   if (MODE == MODE_GAT && (P.H == 1 || P.H == 2 || P.H == 8) && aligned16(P.attn_row) &&
       aligned16(P.attn_col) && aligned16(P.edge_mask) && aligned16(P.edge_max) && aligned16(P.edge_sum))
     ht = P.H;
+  // four heads: narrow rows (steady) take the per-head-vector phase B too -- it is the one that puts
+  // up to four short rows into a pass; wide rows keep the float4 branch with its row cache
+  // (DGNN_FWD_HT4=1 / 0 forces either, A/B runs)
+  if (MODE == MODE_GAT && P.H == 4 && vec4 && ns == 1 && aligned16(P.attn_row) && aligned16(P.attn_col) &&
+      aligned16(P.edge_mask) && aligned16(P.edge_max) && aligned16(P.edge_sum) &&
+      env_int("DGNN_FWD_HT4", steady ? 1 : 0) != 0)
+    ht = 4;
 #define DGNN_FWD_CASE(VECV, NSV, HTV, STV)                                                     \
   if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV && steady == STV) {                     \
     if (MODE == MODE_GAT && timing_on())                                                       \
@@ -138,6 +145,7 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   DGNN_FWD_CASES(0)
   if (MODE == MODE_GAT) {
     DGNN_FWD_CASES(1) DGNN_FWD_CASES(2) DGNN_FWD_CASES(8)
+    DGNN_FWD_CASE(4, 1, 4, true) DGNN_FWD_CASE(4, 1, 4, false)
   }
 #undef DGNN_FWD_CASES
 #undef DGNN_FWD_CASE

@@ -93,7 +93,7 @@ def layer(workload="products"):
                       "torch_chain_ms": round(t_plain, 3)}), flush=True)
 
 
-SHAPES = ((1, 47), (1, 48), (1, 64), (1, 16), (8, 8), (1, 7), (8, 32), (2, 64), (4, 41), (4, 64), (8, 64), (4, 128), (4, 256))
+SHAPES = ((1, 47), (1, 48), (1, 64), (1, 16), (8, 8), (4, 16), (2, 32), (1, 7), (8, 32), (2, 64), (4, 41), (4, 64), (8, 64), (4, 128), (4, 256))
 
 
 def shapes(workload="products"):
