@@ -177,6 +177,31 @@ def test_gat_negative_score_pair_replaces_the_edge_gradient_round_trip(nat, name
     assert_close(host(plain[1]), gr64, "edge-gradient path: grad_attn_row", mass=m_gr)
 
 
+@pytest.mark.parametrize("name", ["deg_edges", "powerlaw256", "rmat4k", "tiny"])
+@pytest.mark.parametrize("h,f", [(1, 64), (1, 16), (2, 32), (4, 16), (8, 8), (8, 32), (1, 48)])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_gat_forward_short_rows_batched_four_per_pass_keeps_every_bit(nat, name, h, f, p, monkeypatch):
+    """The softmax phase of the per-head-vector kernels puts up to four rows of at most 16 edges into
+    one pass, one per DPP row (csrc/gather_fast.hpp): the lanes of a row and the reduction tree
+    inside it are those of the one-row pass, so every output of the forward -- statistics, weights
+    (through out_feat), the negative-score pair -- is bit-identical with the batching off."""
+    g = GRAPHS[name]
+    in_feat, attn_row, attn_col, _ = gat_inputs(g["n"], h, f, seed=5)
+    mask = np.random.default_rng(2).random((g["nnz"], h), dtype=np.float32) if p > 0 else None
+    G = gdev(g)
+    x, ar, ac = dev(in_feat), dev(attn_row), dev(attn_col)
+    dm = dev(mask) if mask is not None else None
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DGNN_FWD_BATCH4", flag)
+        res[flag] = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, edge_mask=dm, neg=True)
+    for a, b, what in zip(res["1"], res["0"], ("out_feat", "edge_max", "edge_sum", "edge_mask", "out_neg", "a_neg")):
+        if a is None or b is None:
+            assert a is None and b is None, what
+        else:
+            assert torch.equal(a, b), what
+
+
 def test_gat_negative_score_pair_shapes_without_it(nat):
     """Rows that are not float4 (f % 4 != 0) and more than eight heads have no pair: neg=True
     returns None for both and the backward works as before."""
