@@ -258,8 +258,14 @@ def main():
     # a process group also for ONE rank when DGNN_DIST_FORCE_COLLECTIVES=1 (rehearsal of the whole
     # multi-GPU path, RCCL calls included, on a one-GPU box; launch through torch.distributed.run)
     use_pg = world > 1 or (os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
+    json_fd = None
     if use_pg:
         import torch.distributed as dist
+        # RCCL writes a version banner to stdout (fd 1, from C) when its first communicator comes up:
+        # keep stdout for the ONE JSON line by pointing fd 1 at stderr for everything else
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     device = torch.device(f"cuda:{local_rank}")
@@ -476,7 +482,10 @@ def main():
                                     "value": nnz / (ms_other * 1e-3)}
         if not args.no_cpu_baseline and world == 1 and not args.simulate_rank:      # a reported baseline of the N = 1 run only
             line["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(line), flush=True)
+        if json_fd is None:
+            print(json.dumps(line), flush=True)
+        else:
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_pg:
         torch.distributed.destroy_process_group()
 
