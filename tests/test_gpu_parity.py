@@ -202,6 +202,50 @@ def test_gat_forward_short_rows_batched_four_per_pass_keeps_every_bit(nat, name,
             assert torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_gat_fuzz_degree_patterns_against_the_oracle(nat, seed, monkeypatch):
+    """Random degree sequences aimed at the row logic of the neighbour-grouped kernels -- runs of short
+    rows (the four-rows-per-pass softmax phase), empty rows between them, rows of exactly 16 / 17 /
+    64 / 65 edges, a long row, short rows straddling group boundaries of 16 ... 256 edges -- with a
+    random head x feature shape and dropout on or off: forward (with the negative-score pair) and
+    backward against the float64 oracle."""
+    from util import degree_graph
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(40, 260))
+    pool = np.array([0, 0, 1, 1, 2, 3, 4, 5, 8, 12, 15, 16, 16, 17, 20, 31, 33, 64, 65])
+    deg = rng.choice(pool, size=n)
+    deg = np.minimum(deg, n)
+    if seed % 3 == 0:
+        deg[int(rng.integers(0, n))] = min(n, 180)
+    if seed % 4 == 1:
+        deg[: n // 3] = rng.integers(1, 5, n // 3)               # a long run of very short rows
+    g = degree_graph(n, [int(d) for d in deg], seed)
+    h, f = [(1, 64), (1, 16), (8, 8), (2, 32), (4, 16), (1, 48), (8, 32), (4, 64), (2, 12), (1, 4)][seed % 10]
+    p = 0.5 if seed % 2 else 0.0
+    monkeypatch.setenv("DGNN_FWD_L", str([16, 32, 64, 128, 256][seed % 5]))
+    monkeypatch.setenv("DGNN_BWD_L", str([64, 128, 256][seed % 3]))
+    slope = 0.2
+    in_feat, attn_row, attn_col, grad = gat_inputs(n, h, f, seed=seed)
+    mask = rng.random((g["nnz"], h), dtype=np.float32) if p > 0 else None
+    G = gdev(g)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    dm = dev(mask) if mask is not None else None
+    out, emax, esum, emask, out_neg, a_neg = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], slope, x, p,
+                                                                    edge_mask=dm, neg=True)
+    o64, emax64, esum64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope, in_feat, p, mask)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p)
+    assert_close(host(out), o64, "fuzz: out_feat", mass=m_out)
+    nonempty = np.diff(g["row_ptr"]) > 0
+    assert_close(host(emax)[nonempty], emax64[nonempty], "fuzz: edge_max")
+    assert_close(host(esum), esum64, "fuzz: edge_sum", mass=esum64)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(slope, p, g["row_ptr"], g["col_ind"], mask, in_feat, attn_row, attn_col, grad)
+    got = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                  emax, esum, emask, x, ar, ac, go, out_feat=out, out_neg=out_neg, a_neg=a_neg)
+    assert_close(host(got[0]), gf64, "fuzz: grad_feat", mass=m_gf)
+    assert_close(host(got[1]), gr64, "fuzz: grad_attn_row", mass=m_gr)
+    assert_close(host(got[2]), gc64, "fuzz: grad_attn_col", mass=m_gc)
+
+
 def test_gat_negative_score_pair_shapes_without_it(nat):
     """Rows that are not float4 (f % 4 != 0) and more than eight heads have no pair: neg=True
     returns None for both and the backward works as before."""
