@@ -7,8 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from dgnn_amd.dist import partition_bounds
 dev = torch.device("cuda:0")
-g = bench.build_graph("products", dev)
+labels = sys.argv[1] if len(sys.argv) > 1 else "scrambled"      # or "natural"
+g = bench.build_graph("products", dev, labels=labels)
 n = g["n"]
+print("node labels:", labels)
 for world in (2, 4, 8):
     b = partition_bounds(g["row_ptr"], world)
     rows = []
