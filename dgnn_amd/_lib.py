@@ -35,6 +35,7 @@ SIGNATURES = {
     "dgnn_gat_forward_tiles_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_gat_forward_tiles": (_i, [_i, _i, _i, _i, _f] + [_vp] * 6 + [_i, _i] + [_vp] * 3 + [_vp, _sz, _vp]),
     "dgnn_gat_row_dot": (_i, [_i, _i, _i] + [_vp] * 3 + [_vp]),
+    "dgnn_gat_row_stats": (_i, [_i, _i, _i, _f] + [_vp] * 9 + [_vp]),
     "dgnn_gat_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "dgnn_gat_backward": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 19 + [_vp, _sz, _vp]),
     "dgnn_gat_backward_packed": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 13 + [_vp, _sz, _vp]),

@@ -152,7 +152,12 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   if (MODE == MODE_GAT) timer_mark(0, 1, st);
   DGNN_LAUNCH_CHECK();
   if (P.T > 1) {
-    hipLaunchKernelGGL(k_fast_fixup<MODE>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+    // two launches: long rows first merge groups of DGNN_FIX_C pieces (phase 0), then everything (phase 1)
+    if (P.T - 1 > DGNN_FIX_C) {
+      hipLaunchKernelGGL(k_fast_fixup<MODE>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 0);
+      DGNN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_fast_fixup<MODE>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 1);
     DGNN_LAUNCH_CHECK();
   }
   return DGNN_OK;
@@ -478,6 +483,38 @@ int dgnn_gat_row_dot(int m, int h, int f, const float *grad, const float *out_fe
   if (!grad || !out_feat || !row_dot) return DGNN_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_gat_row_dot, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
                      (hipStream_t)stream, m, h, f, grad, out_feat, row_dot);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+
+int dgnn_gat_row_stats(int m, int h, int f, float negative_slope, const float *attn_row, const float *edge_max,
+                       const float *edge_sum, const float *grad, const float *out_feat, const float *out_neg,
+                       const float *a_neg, float *row_stat, float *grad_attn_row, void *stream) {
+  if (m < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if (m == 0) return DGNN_OK;
+  if (!attn_row || !edge_max || !edge_sum || !grad || !out_feat || !row_stat) return DGNN_ERR_BAD_ARG;
+  if ((out_neg == nullptr) != (a_neg == nullptr) || (out_neg != nullptr && grad_attn_row == nullptr))
+    return DGNN_ERR_BAD_ARG;
+  const int vec = (f % 4 == 0 && aligned16(grad) && aligned16(out_feat) && (out_neg == nullptr || aligned16(out_neg))) ? 4 : 1;
+  if (h > 8 || bwd_lanes_per_head(f, vec) > DGNN_WAVE || !aligned16(row_stat)) return DGNN_ERR_UNSUPPORTED;
+  if (out_neg != nullptr && vec != 4) return DGNN_ERR_UNSUPPORTED;
+  BwdParams P = {};
+  P.m = m; P.H = h; P.F = f; P.HF = h * f; P.vec = vec; P.fv = bwd_lanes_per_head(f, vec); P.hpp = DGNN_WAVE / P.fv;
+  P.slope = negative_slope;
+  P.attn_row = attn_row; P.edge_max = edge_max; P.edge_sum = edge_sum; P.grad = grad; P.out_feat = out_feat;
+  P.out_neg = out_neg; P.a_neg = a_neg; P.grad_attn_row = grad_attn_row; P.rowstat = (float4 *)row_stat;
+  hipStream_t st = (hipStream_t)stream;
+  int rs = 1;
+  while (rs < h * P.fv) rs <<= 1;
+  if (vec == 4 && rs <= 32) {
+    const long long rows_per_wave = (long long)(DGNN_WAVE / rs) * 4;
+    hipLaunchKernelGGL(k_bwd_rowstat_packed, dim3(blocks_for_waves((m + rows_per_wave - 1) / rows_per_wave)),
+                       dim3(DGNN_BLOCK), 0, st, P, rs);
+  } else if (vec == 4) {
+    hipLaunchKernelGGL(k_bwd_rowstat<4>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
+  } else {
+    hipLaunchKernelGGL(k_bwd_rowstat<1>, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0, st, P);
+  }
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

@@ -1005,8 +1005,20 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
 // Merge the partial slots of rows cut by a group boundary.  One wave per boundary t (1..T-1);
 // the wave of the FIRST boundary inside a row owns that row's merge, pieces are combined in
 // group order: M = max m_p, S = sum s_p*exp(m_p-M), out = sum acc_p*exp(m_p-M) / S.
+//
+// A hub row is cut into hundreds of pieces and one wave walking them is a dependent chain of loads
+// (0.2 ms for the longest row of the products shape -- and again in every chunk of a partitioned
+// block).  Rows of more than DGNN_FIX_C pieces are therefore merged in two launches: in `phase` 0
+// the waves of every DGNN_FIX_C-th boundary inside such a row merge their DGNN_FIX_C pieces into
+// the first of them, in place and unnormalised (a partial triple (M, S, acc) is itself a slot);
+// in phase 1 the owner merges those.  The tree depends on the piece count alone: deterministic.
+// (Rows wider than one lane pass keep the one-level walk: their lanes read the piece statistics
+// once per pass.)
+#ifndef DGNN_FIX_C
+#define DGNN_FIX_C 16
+#endif
 template <int MODE>
-__global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
+__global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int phase) {
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) + 1;
   if (t >= P.T) return;
@@ -1015,71 +1027,108 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
   const int rs = uniform_i32(P.row_ptr[r]), re = uniform_i32(P.row_ptr[r + 1]);
   const long long edge = (long long)t * L;
   if (rs >= edge) return;                    // the row starts exactly on the boundary: not cut here
-  if (rs < edge - L) return;                 // an earlier boundary owns this row
+  const int t0 = rs / L + 1;                 // the first boundary inside the row: its wave owns the merge
   const int t_last = (re - 1) / L;
-  // piece i = 0 is the tail slot of group t-1, pieces 1.. are the head slots of groups t..t_last
-  const int npieces = t_last - t + 2;
-  auto slot_of = [&](int i) -> const float * {
-    const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
-    return P.slots + (size_t)s * P.slot_stride;
-  };
+  // piece i = 0 is the tail slot of group t0-1, pieces 1.. are the head slots of groups t0..t_last
+  const int npieces = t_last - t0 + 2;
   const bool vec4 = (P.F % 4 == 0) && ((((uintptr_t)P.out) & 15u) == 0);
   const int vw = vec4 ? 4 : 1;
   const int nslots = P.HF / vw;
+  const bool two_level = npieces > DGNN_FIX_C && nslots <= DGNN_WAVE;
+  int first = 0, cnt = npieces, stride = 1;
+  if (phase == 0) {
+    if (!two_level) return;
+    const int d = t - t0;
+    int k;
+    if (d == 0) k = 0;
+    else if ((d + 1) % DGNN_FIX_C == 0) k = (d + 1) / DGNN_FIX_C;
+    else return;
+    first = k * DGNN_FIX_C;
+    cnt = min(DGNN_FIX_C, npieces - first);
+    if (cnt <= 1) return;                    // a lone last piece is its own partial
+  } else {
+    if (t != t0) return;                     // an earlier boundary owns this row
+    if (two_level) {
+      stride = DGNN_FIX_C;
+      cnt = (npieces + DGNN_FIX_C - 1) / DGNN_FIX_C;
+    }
+  }
+  auto slot_of = [&](int i) -> float * {     // i-th piece of this wave's list
+    const int pi = first + i * stride;
+    const int s = (pi == 0) ? 2 * (t0 - 1) + 1 : 2 * (t0 + pi - 1);
+    return P.slots + (size_t)s * P.slot_stride;
+  };
+  const bool final_pass = phase != 0;
   for (int fb = 0; fb * DGNN_WAVE < nslots; ++fb) {
     const int vs = fb * DGNN_WAVE + lane;
     const bool active = vs < nslots;
     const int fid = (active ? vs : 0) * vw;
     const int head = fid / P.F;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int FB = 8;
     if (MODE == MODE_GAT) {
-      // A hub row is cut into hundreds of pieces: the loads of FB pieces are issued together, the
-      // arithmetic then runs over them in piece order (same sums as one piece at a time).
-      constexpr int FB = 8;
+      // the loads of FB pieces are issued together, the arithmetic then runs over them in piece
+      // order (same sums as one piece at a time)
       float M = DGNN_NEG_INIT;
-      for (int i0 = 0; i0 < npieces; i0 += FB) {
+      for (int i0 = 0; i0 < cnt; i0 += FB) {
         float m[FB];
 #pragma unroll
-        for (int j = 0; j < FB; ++j) m[j] = slot_of(min(i0 + j, npieces - 1))[P.HF + head];
+        for (int j = 0; j < FB; ++j) m[j] = slot_of(min(i0 + j, cnt - 1))[P.HF + head];
 #pragma unroll
         for (int j = 0; j < FB; ++j) M = fmaxf(M, m[j]);
       }
       float S = 0.f;
-      for (int i0 = 0; i0 < npieces; i0 += FB) {
-        float m[FB], sm[FB];
-        float4 v[FB];
+      // the negative-score aggregate and weight sum of the cut row ride the same batches (float4 rows only)
+      const bool neg = P.out_neg != nullptr;
+      float an = 0.f, nacc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i0 = 0; i0 < cnt; i0 += FB) {
+        float m[FB], sm[FB], sa[FB];
+        float4 v[FB], vn[FB];
 #pragma unroll
         for (int j = 0; j < FB; ++j) {
-          const float *sp = slot_of(min(i0 + j, npieces - 1));
+          const float *sp = slot_of(min(i0 + j, cnt - 1));
           m[j] = sp[P.HF + head];
           sm[j] = sp[P.HF + H + head];
           if (vec4) v[j] = *(const float4 *)(sp + fid);
           else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
+          if (neg) {
+            sa[j] = sp[P.HF + 2 * H + head];
+            vn[j] = *(const float4 *)(sp + P.slot_neg + fid);
+          }
         }
 #pragma unroll
         for (int j = 0; j < FB; ++j)
-          if (i0 + j < npieces) {
+          if (i0 + j < cnt) {
             const float fct = expf(m[j] - M);
             S = fmaf(sm[j], fct, S);
             acc[0] = fmaf(v[j].x, fct, acc[0]); acc[1] = fmaf(v[j].y, fct, acc[1]);
             acc[2] = fmaf(v[j].z, fct, acc[2]); acc[3] = fmaf(v[j].w, fct, acc[3]);
+            if (neg) {
+              an = fmaf(sa[j], fct, an);
+              nacc[0] = fmaf(vn[j].x, fct, nacc[0]); nacc[1] = fmaf(vn[j].y, fct, nacc[1]);
+              nacc[2] = fmaf(vn[j].z, fct, nacc[2]); nacc[3] = fmaf(vn[j].w, fct, nacc[3]);
+            }
           }
       }
-      if (P.out_neg != nullptr) {
-        // the negative-score aggregate and weight sum of the cut row: same merge (float4 rows only)
-        float an = 0.f, nacc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < npieces; ++i) {
-          const float *sp = slot_of(i);
-          const float fct = expf(sp[P.HF + head] - M);
-          const float4 v = *(const float4 *)(sp + P.slot_neg + fid);
-          an = fmaf(sp[P.HF + 2 * H + head], fct, an);
-          nacc[0] = fmaf(v.x, fct, nacc[0]); nacc[1] = fmaf(v.y, fct, nacc[1]);
-          nacc[2] = fmaf(v.z, fct, nacc[2]); nacc[3] = fmaf(v.w, fct, nacc[3]);
-        }
+      if (!final_pass) {
+        // the partial triple replaces the first piece (every lane has consumed its loads: the values
+        // stored depend on them)
+        float *sp = slot_of(0);
         if (active) {
-          *(float4 *)(P.out_neg + (size_t)r * P.HF + fid) = make_float4(nacc[0] / S, nacc[1] / S, nacc[2] / S, nacc[3] / S);
-          if (fid == head * P.F) P.a_neg[(size_t)r * H + head] = an / S;
+          if (vec4) *(float4 *)(sp + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          else sp[fid] = acc[0];
+          if (neg) *(float4 *)(sp + P.slot_neg + fid) = make_float4(nacc[0], nacc[1], nacc[2], nacc[3]);
+          if (fid == head * P.F) {
+            sp[P.HF + head] = M;
+            sp[P.HF + H + head] = S;
+            if (neg) sp[P.HF + 2 * H + head] = an;
+          }
         }
+        continue;
+      }
+      if (neg && active) {
+        *(float4 *)(P.out_neg + (size_t)r * P.HF + fid) = make_float4(nacc[0] / S, nacc[1] / S, nacc[2] / S, nacc[3] / S);
+        if (fid == head * P.F) P.a_neg[(size_t)r * H + head] = an / S;
       }
       if (active) {
         if (vec4)
@@ -1093,18 +1142,25 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P) {
         }
       }
     } else {
-      constexpr int FB = 8;
-      for (int i0 = 0; i0 < npieces; i0 += FB) {
+      for (int i0 = 0; i0 < cnt; i0 += FB) {
         float4 v[FB];
 #pragma unroll
         for (int j = 0; j < FB; ++j) {
-          const float *sp = slot_of(min(i0 + j, npieces - 1));
+          const float *sp = slot_of(min(i0 + j, cnt - 1));
           if (vec4) v[j] = *(const float4 *)(sp + fid);
           else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < FB; ++j)
-          if (i0 + j < npieces) { acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w; }
+          if (i0 + j < cnt) { acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w; }
+      }
+      if (!final_pass) {
+        float *sp = slot_of(0);
+        if (active) {
+          if (vec4) *(float4 *)(sp + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          else sp[fid] = acc[0];
+        }
+        continue;
       }
       if (P.sum_heads) {     // host guarantees float4 lanes and a single lane pass here
         store_row_summed(P, r, active, head, (size_t)(fid - head * P.F), make_float4(acc[0], acc[1], acc[2], acc[3]));

@@ -254,6 +254,33 @@ Tensor gat_inference(const Tensor &attn_row, const Tensor &attn_col, const Tenso
 }
 
 // -> S [m,h] = <grad[r,h,:], out_feat[r,h,:]> (the row term of the backward)
+// -> (row_stat [m,h,4], grad_attn_row [m,h] or None), or None where the kernels have no such pass
+py::object gat_row_stats(double negative_slope, const Tensor &attn_row, const Tensor &edge_max, const Tensor &edge_sum,
+                         const Tensor &grad, const Tensor &out_feat, const c10::optional<Tensor> &out_neg,
+                         const c10::optional<Tensor> &a_neg) {
+  f32(grad, "grad", 3), f32(out_feat, "out_feat", 3), f32(attn_row, "attn_row", 2), f32(edge_max, "edge_max", 2),
+      f32(edge_sum, "edge_sum", 2);
+  if (grad.sizes() != out_feat.sizes()) fail("gat_row_stats: grad and out_feat must have the same shape");
+  const int m = as_int(grad.size(0), "rows"), h = as_int(grad.size(1), "heads"), f = as_int(grad.size(2), "features");
+  for (const Tensor *t : {&attn_row, &edge_max, &edge_sum})
+    if (t->size(0) != m || t->size(1) != h) fail("gat_row_stats: attn_row / edge_max / edge_sum must be [m,h]");
+  if (given(out_neg) != given(a_neg)) fail("gat_row_stats: out_neg and a_neg come together");
+  if (given(out_neg)) {
+    f32(*out_neg, "out_neg", 3), f32(*a_neg, "a_neg", 2);
+    if (out_neg->sizes() != grad.sizes() || a_neg->size(0) != m || a_neg->size(1) != h)
+      fail("gat_row_stats: out_neg must be [m,h,f] and a_neg [m,h]");
+  }
+  c10::DeviceGuard guard(grad.device());
+  Tensor stat = new_f32({m, h, 4}, grad);
+  Tensor gr = given(out_neg) ? new_f32({m, h}, grad) : Tensor();
+  const int rc = API(dgnn_gat_row_stats)(m, h, f, (float)negative_slope, fp(attn_row), fp(edge_max), fp(edge_sum),
+                                         fp(grad), fp(out_feat), fp(out_neg), fp(a_neg), fo(stat),
+                                         given(out_neg) ? fo(gr) : nullptr, stream_of(grad));
+  if (rc == DGNN_ERR_UNSUPPORTED) return py::none();
+  check_rc(rc, "dgnn_gat_row_stats");
+  return py::make_tuple(stat, given(out_neg) ? py::cast(gr) : py::none());
+}
+
 Tensor gat_row_dot(const Tensor &grad, const Tensor &out_feat) {
   f32(grad, "grad", 3), f32(out_feat, "out_feat", 3);
   if (grad.sizes() != out_feat.sizes()) fail("gat_row_dot: grad and out_feat must have the same shape");
@@ -952,6 +979,10 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("idx"), arg("out") = py::none());
   def(m, "gat_row_dot", &gat_row_dot, "grad, out_feat", "-> S [m,h] = <grad[r,h,:], out_feat[r,h,:]>", arg("grad"),
       arg("out_feat"));
+  def(m, "gat_row_stats", &gat_row_stats, "negative_slope, attn_row, edge_max, edge_sum, grad, out_feat, out_neg=None, a_neg=None",
+      "-> (row_stat [m,h,4], grad_attn_row or None) in one pass over the rows; None where unsupported", arg("negative_slope"),
+      arg("attn_row"), arg("edge_max"), arg("edge_sum"), arg("grad"), arg("out_feat"), arg("out_neg") = py::none(),
+      arg("a_neg") = py::none());
   def(m, "gat_backward", &gat_backward,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, "
       "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",

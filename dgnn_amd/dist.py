@@ -84,6 +84,10 @@ class _NativeOps:
     def row_dot(self, grad, out):
         return self._gat.gat_row_dot(grad, out)
 
+    def row_stats(self, slope, attn_row, edge_max, edge_sum, grad, out, out_neg=None, a_neg=None):
+        """(packed row records [m,h,4], grad_attn_row or None) in one pass, or None (unsupported shape)."""
+        return self._gat.gat_row_stats(slope, attn_row, edge_max, edge_sum, grad, out, out_neg, a_neg)
+
     def gat_backward(self, slope, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
                      in_feat, attn_row, attn_col, grad, row_dot, out=None):
         return self._gat.gat_backward(slope, 0.0, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max,
@@ -467,9 +471,21 @@ class PartitionedGAT:
         """-> (grad_feat_loc [n_loc,H,F], grad_attn_row_loc [n_loc,H], grad_attn_col_loc [n_loc,H])."""
         in_feat_loc, attn_row_loc, attn_col_loc, out, emax, esum, slope = self._ctx
         grad_out_loc = grad_out_loc.contiguous()
-        S_loc = self.ops.row_dot(grad_out_loc, out)
-        # the 16-byte records the column-gather kernel reads per (edge, head): they travel packed
-        stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=2).contiguous()   # [n_loc,H,4]
+        neg_pair = getattr(self, "_neg", None) if self.mode == "halo" else None
+        # the 16-byte records the column-gather kernel reads per (edge, head): they travel packed.
+        # One kernel makes them (and, from the forward's negative-score pair, this rank's
+        # grad_attn_row) from a single read of grad / out / out_neg; back ends without it take the
+        # row dots one by one.
+        fused = None
+        if hasattr(self.ops, "row_stats"):
+            fused = self.ops.row_stats(slope, attn_row_loc, emax, esum, grad_out_loc, out,
+                                       *(neg_pair if neg_pair is not None else (None, None)))
+        if fused is not None:
+            stat_loc, fused_gr = fused
+        else:
+            S_loc = self.ops.row_dot(grad_out_loc, out)
+            stat_loc = torch.stack((attn_row_loc, emax, esum, S_loc), dim=2).contiguous()   # [n_loc,H,4]
+            fused_gr = None
         if self.mode == "halo":
             side = self.b_side
             grad_tab, stat_tab = self._table(side, grad_out_loc, "grad"), self._table(side, stat_loc, "stat")
@@ -481,9 +497,13 @@ class PartitionedGAT:
         #   (1 - slope) (S * a_neg - <grad, out_neg>)      (include/dgnn_hip.h, dgnn_gat_forward)
         # so the column chunks produce no edge gradients and no partial rows travel back.
         local_gr = None
-        if self.mode == "halo" and getattr(self, "_neg", None) is not None:
-            out_neg, a_neg = self._neg
-            local_gr = (1.0 - slope) * (S_loc * a_neg - self.ops.row_dot(grad_out_loc, out_neg))
+        if neg_pair is not None:
+            if fused_gr is not None:
+                local_gr = fused_gr
+            else:
+                out_neg, a_neg = neg_pair
+                S_of = stat_loc[:, :, 3] if fused is not None else S_loc
+                local_gr = (1.0 - slope) * (S_of * a_neg - self.ops.row_dot(grad_out_loc, out_neg))
         gr_tab = None if local_gr is not None else \
             torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
         gf = torch.empty_like(in_feat_loc)

@@ -134,6 +134,18 @@ int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
 int dgnn_gat_row_dot(int m, int h, int f, const float *grad, const float *out_feat,
                      float *row_dot, void *stream);
 
+/* The whole per-row pass of the fused backward in one launch, for the same callers: row_stat
+ * [m,h,4] = {attn_row, edge_max, edge_sum, S} per (row, head) -- the 16-byte records
+ * dgnn_gat_backward_packed reads -- and, given the forward's negative-score pair, grad_attn_row
+ * [m,h] = (1 - slope) (S a_neg - <grad, out_neg>) (fused_backward_kernel :952-967 restated per
+ * row, see dgnn_gat_forward).  One read of grad, out_feat and out_neg.  out_neg / a_neg /
+ * grad_attn_row may be NULL together.  DGNN_ERR_UNSUPPORTED outside h <= 8, f <= 256 (64 when f is
+ * not a multiple of four; the pair needs float4 rows): use dgnn_gat_row_dot then. */
+int dgnn_gat_row_stats(int m, int h, int f, float negative_slope, const float *attn_row,
+                       const float *edge_max, const float *edge_sum, const float *grad,
+                       const float *out_feat, const float *out_neg, const float *a_neg,
+                       float *row_stat, float *grad_attn_row, void *stream);
+
 /* Scratch for dgnn_gat_backward.  have_row_term != 0 when the caller will pass out_feat or
  * row_dot (then no recompute buffer is needed). */
 size_t dgnn_gat_backward_workspace_bytes(int m, int n, int nnz, int h, int f, int have_row_term);
