@@ -637,8 +637,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
 }
 
 // Merge the partial slots of columns cut by a group boundary (plain sums, fixed order).
+#ifndef DGNN_FIX_C
+#define DGNN_FIX_C 16
+#endif
 template <int VEC>
-__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
+__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P, int phase) {
   using V = VecT<VEC>;
   using vec_t = typename V::type;
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block()) + 1;
@@ -648,35 +651,65 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P) {
   const int cs = uniform_i32(P.col_ptr[c]), ce = uniform_i32(P.col_ptr[c + 1]);
   const long long edge = (long long)t * L;
   if (cs >= edge) return;
-  if (cs < edge - L) return;
+  const int t0 = cs / L + 1;                 // the first boundary inside the column owns its merge
   const int t_last = (ce - 1) / L;
-  const int npieces = t_last - t + 2;
+  const int npieces = t_last - t0 + 2;
+  // hub columns (more than DGNN_FIX_C pieces) in two launches, like k_fast_fixup: phase 0 sums
+  // groups of DGNN_FIX_C pieces into the first of each group, phase 1 sums those
+  const bool two_level = npieces > DGNN_FIX_C;
+  int first = 0, cnt = npieces, stride = 1;
+  if (phase == 0) {
+    if (!two_level) return;
+    const int d = t - t0;
+    int k;
+    if (d == 0) k = 0;
+    else if ((d + 1) % DGNN_FIX_C == 0) k = (d + 1) / DGNN_FIX_C;
+    else return;
+    first = k * DGNN_FIX_C;
+    cnt = min(DGNN_FIX_C, npieces - first);
+    if (cnt <= 1) return;
+  } else {
+    if (t != t0) return;
+    if (two_level) {
+      stride = DGNN_FIX_C;
+      cnt = (npieces + DGNN_FIX_C - 1) / DGNN_FIX_C;
+    }
+  }
+  auto slot_of = [&](int i) -> float * {
+    const int pi = first + i * stride;
+    const int s = (pi == 0) ? 2 * (t0 - 1) + 1 : 2 * (t0 + pi - 1);
+    return P.slots + (size_t)s * P.slot_stride;
+  };
   for (int hb = 0; hb < H; hb += P.hpp) {
     const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
     vec_t acc = V::zero();
     float dsum = 0.f;
-    // loads of FB pieces in flight together, sums in piece order (a hub column has hundreds)
+    // loads of FB pieces in flight together, sums in piece order
     constexpr int FB = 8;
     const bool want_d = P.grad_attn_col != nullptr;
-    for (int i0 = 0; i0 < npieces; i0 += FB) {
+    for (int i0 = 0; i0 < cnt; i0 += FB) {
       vec_t v[FB];
       float d[FB];
 #pragma unroll
       for (int j = 0; j < FB; ++j) {
-        const int i = min(i0 + j, npieces - 1);
-        const int s = (i == 0) ? 2 * (t - 1) + 1 : 2 * (t + i - 1);
-        const float *sp = P.slots + (size_t)s * P.slot_stride;
+        const float *sp = slot_of(min(i0 + j, cnt - 1));
         v[j] = *(const vec_t *)(sp + ln.off);
         d[j] = want_d ? sp[P.HF + ln.head] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < FB; ++j)
-        if (i0 + j < npieces) {
+        if (i0 + j < cnt) {
           vec_add<VEC>(acc, v[j]);
           dsum += d[j];
         }
     }
-    if (ln.active) {
+    if (phase == 0) {
+      float *sp = slot_of(0);
+      if (ln.active) {
+        *(vec_t *)(sp + ln.off) = acc;
+        if (ln.leader && want_d) sp[P.HF + ln.head] = dsum;
+      }
+    } else if (ln.active) {
       *(vec_t *)(P.grad_feat + (size_t)c * P.HF + ln.off) = acc;
       if (ln.leader && P.grad_attn_col != nullptr) P.grad_attn_col[(size_t)c * H + ln.head] = dsum;
     }

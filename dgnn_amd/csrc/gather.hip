@@ -631,9 +631,11 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
       DGNN_LAUNCH_CHECK();
       if (P.T > 1) {
         if (vec == 4)
-          hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+          { if (P.T - 1 > DGNN_FIX_C) hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 0);
+          hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 1); }
         else
-          hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+          { if (P.T - 1 > DGNN_FIX_C) hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 0);
+          hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 1); }
         DGNN_LAUNCH_CHECK();
       }
     }
@@ -906,9 +908,11 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
     DGNN_LAUNCH_CHECK();
     if (P.T > 1) {
       if (vec == 4)
-        hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+        { if (P.T - 1 > DGNN_FIX_C) hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 0);
+          hipLaunchKernelGGL(k_bwd_fixup<4>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 1); }
       else
-        hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P);
+        { if (P.T - 1 > DGNN_FIX_C) hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 0);
+          hipLaunchKernelGGL(k_bwd_fixup<1>, dim3(blocks_for_waves(P.T - 1)), dim3(DGNN_BLOCK), 0, st, P, 1); }
       DGNN_LAUNCH_CHECK();
     }
   }
