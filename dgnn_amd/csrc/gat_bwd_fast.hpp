@@ -648,6 +648,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P, int phase
   if (t >= P.T) return;
   const int L = P.L, H = P.H;
   const int c = uniform_i32(P.task_col0[t]);
+  if (phase == 0) {        // cheap necessary condition first (see k_fast_fixup)
+    const int back = uniform_i32(P.task_col0[max(t - (DGNN_FIX_C - 1), 0)]);
+    const int ahead = uniform_i32(P.task_col0[min(t + DGNN_FIX_C - 2, P.T - 1)]);
+    if (back != c && ahead != c) return;
+  }
   const int cs = uniform_i32(P.col_ptr[c]), ce = uniform_i32(P.col_ptr[c + 1]);
   const long long edge = (long long)t * L;
   if (cs >= edge) return;

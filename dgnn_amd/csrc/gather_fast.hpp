@@ -1024,6 +1024,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
   if (t >= P.T) return;
   const int L = P.L, H = P.H;
   const int r = uniform_i32(P.task_row0[t]);
+  if (phase == 0) {
+    // cheap necessary condition before the dependent row_ptr loads: a row of more than DGNN_FIX_C
+    // pieces also covers the start of the group DGNN_FIX_C - 1 boundaries back (first-level waves
+    // k >= 1) or DGNN_FIX_C - 2 ahead (k = 0); nearly every wave of this sweep leaves here
+    const int back = uniform_i32(P.task_row0[max(t - (DGNN_FIX_C - 1), 0)]);
+    const int ahead = uniform_i32(P.task_row0[min(t + DGNN_FIX_C - 2, P.T - 1)]);
+    if (back != r && ahead != r) return;
+  }
   const int rs = uniform_i32(P.row_ptr[r]), re = uniform_i32(P.row_ptr[r + 1]);
   const long long edge = (long long)t * L;
   if (rs >= edge) return;                    // the row starts exactly on the boundary: not cut here
