@@ -34,6 +34,7 @@ Exchange (``mode``):
 Set with ``DGNN_DIST_MODE``.  gloo (CPU tests) takes the same code path; CUDA tensors under a
 non-NCCL backend are staged through the host.
 """
+import contextlib
 import os
 
 import torch
@@ -326,6 +327,28 @@ class PartitionedGAT:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def _chunk_streams(self, dev):
+        """Two compute streams taken in turn by the chunks of a pass (GPU, halo mode): a chunk's
+        tail -- the last waves of its gather, the merges of rows cut by group boundaries (a chain
+        of small launches), the next chunk's directory pass -- runs under the next chunk's gather
+        instead of in front of it.  Chunks write disjoint rows, so the order between them is free.
+        DGNN_DIST_TWO_STREAMS=0 keeps every chunk on the caller's stream."""
+        if dev.type != "cuda" or self.chunks < 2 or os.environ.get("DGNN_DIST_TWO_STREAMS", "1") == "0":
+            return None
+        if getattr(self, "_cstreams", None) is None:
+            self._cstreams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        cur = torch.cuda.current_stream(dev)
+        for st in self._cstreams:
+            st.wait_stream(cur)
+        return self._cstreams
+
+    @staticmethod
+    def _join_streams(streams, dev):
+        if streams is not None:
+            cur = torch.cuda.current_stream(dev)
+            for st in streams:
+                cur.wait_stream(st)
+
     def _pack(self, local, h):
         """The rows of ``local`` the peers want for this chunk, as one contiguous message."""
         pack = getattr(self.ops, "pack_rows", None)       # injected test back ends have none
@@ -333,28 +356,34 @@ class PartitionedGAT:
             return pack(local, h.send_idx32)
         return local.index_select(0, h.send_idx)
 
-    def _start_fetch(self, side, tables, locals_):
+    def _start_fetch(self, side, tables, locals_, only=None, skip=()):
         """Start every chunk's exchange, in chunk order: for each chunk the rows the peers need of
         each tensor in ``locals_`` are packed and sent, and the rows this rank needs land directly
         in their place in ``tables`` (no scatter pass).  -> per-chunk (handle list, event).
+        ``only`` restricts the call to those chunks (the others get empty entries); ``skip`` lists
+        (chunk, tensor position) pairs an earlier call has started already.  Every rank makes the
+        same calls in the same order, so the collectives still pair up.
 
         On the GPU the packs run on a SIDE stream (ordered after the current stream once, so the
         inputs are complete): only chunk 0's pack and exchange precede chunk 0's kernels; the packs
         of the later chunks (1.2 ms per step at 8 ranks on the products shape, as much as one gather
         pass) overlap the compute stream instead of sitting in front of it.  DGNN_DIST_PACK_STREAM=0
         issues them on the compute stream as before (A/B runs)."""
-        on_gpu = bool(locals_) and locals_[0].is_cuda and os.environ.get("DGNN_DIST_PACK_STREAM", "1") != "0"
+        first = next((l for l in locals_ if l is not None), None)
+        on_gpu = first is not None and first.is_cuda and os.environ.get("DGNN_DIST_PACK_STREAM", "1") != "0"
         if not on_gpu:
             handles = []
             for s, h in enumerate(side.halos):
                 hs = []
-                for table, local in zip(tables, locals_):
+                for i, (table, local) in enumerate(zip(tables, locals_)):
+                    if (only is not None and s not in only) or (s, i) in skip:
+                        continue
                     send = self._pack(local, h)
                     hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
                                         h.send_counts, async_op=True))
                 handles.append((hs, None))
             return handles
-        dev = locals_[0].device
+        dev = first.device
         if getattr(self, "_pack_stream", None) is None:
             self._pack_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
@@ -363,7 +392,9 @@ class PartitionedGAT:
         with torch.cuda.stream(self._pack_stream):
             for s, h in enumerate(side.halos):
                 hs = []
-                for table, local in zip(tables, locals_):
+                for i, (table, local) in enumerate(zip(tables, locals_)):
+                    if (only is not None and s not in only) or (s, i) in skip:
+                        continue
                     send = self._pack(local, h)
                     hs.append(self._a2a(table[side.offs[s]:side.offs[s] + h.n_needed], send, h.recv_counts,
                                         h.send_counts, async_op=True))
@@ -449,16 +480,19 @@ class PartitionedGAT:
             want_neg = getattr(self.ops, "supports_neg", False) and in_feat_loc.size(-1) % 4 == 0
             out_neg = torch.empty_like(out) if want_neg else None
             a_neg = torch.empty_like(emax) if want_neg else None
+            streams = self._chunk_streams(in_feat_loc.device)
             for s, (a, b, ptr, ind, n_vis) in enumerate(side.blocks):   # every chunk writes its own rows
-                self._wait(handles[s])
-                if want_neg:
-                    res = self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
-                                               out=(out[a:b], emax[a:b], esum[a:b], out_neg[a:b], a_neg[a:b]), neg=True)
-                    if res[3] is None:             # shape outside the pair's kernels: the edge-gradient path
-                        want_neg, out_neg, a_neg = False, None, None
-                else:
-                    self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
-                                         out=(out[a:b], emax[a:b], esum[a:b]))
+                with (torch.cuda.stream(streams[s % 2]) if streams is not None else contextlib.nullcontext()):
+                    self._wait(handles[s])
+                    if want_neg:
+                        res = self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
+                                                   out=(out[a:b], emax[a:b], esum[a:b], out_neg[a:b], a_neg[a:b]), neg=True)
+                        if res[3] is None:             # shape outside the pair's kernels: the edge-gradient path
+                            want_neg, out_neg, a_neg = False, None, None
+                    else:
+                        self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
+                                             out=(out[a:b], emax[a:b], esum[a:b]))
+            self._join_streams(streams, in_feat_loc.device)
             self._neg = (out_neg, a_neg) if want_neg else None
         else:
             in_tab, ac_tab = self._all_gather_rows(in_feat_loc), self._all_gather_rows(attn_col_loc)
@@ -476,6 +510,12 @@ class PartitionedGAT:
         # One kernel makes them (and, from the forward's negative-score pair, this rank's
         # grad_attn_row) from a single read of grad / out / out_neg; back ends without it take the
         # row dots one by one.
+        # The first chunk's exchange is the exposed one, and its big message (grad_out rows) does not
+        # depend on the records: it is started before the row pass and travels under it.
+        early = None
+        if self.mode == "halo" and os.environ.get("DGNN_DIST_EARLY_GRAD", "1") != "0":
+            grad_tab = self._table(self.b_side, grad_out_loc, "grad")
+            early = self._start_fetch(self.b_side, (None, grad_tab), (None, grad_out_loc), only=(0,), skip=((0, 0),))
         fused = None
         if hasattr(self.ops, "row_stats"):
             fused = self.ops.row_stats(slope, attn_row_loc, emax, esum, grad_out_loc, out,
@@ -488,8 +528,13 @@ class PartitionedGAT:
             fused_gr = None
         if self.mode == "halo":
             side = self.b_side
-            grad_tab, stat_tab = self._table(side, grad_out_loc, "grad"), self._table(side, stat_loc, "stat")
-            handles = self._start_fetch(side, (stat_tab, grad_tab), (stat_loc, grad_out_loc))
+            if early is None:
+                grad_tab = self._table(side, grad_out_loc, "grad")
+            stat_tab = self._table(side, stat_loc, "stat")
+            handles = self._start_fetch(side, (stat_tab, grad_tab), (stat_loc, grad_out_loc),
+                                        skip=((0, 1),) if early is not None else ())
+            if early is not None:             # chunk 0 waits for both parts; the later event covers the pack stream
+                handles[0] = (early[0][0] + handles[0][0], handles[0][1])
         else:
             grad_tab, stat_tab = self._all_gather_rows(grad_out_loc), self._all_gather_rows(stat_loc)
             handles = [[]]
@@ -508,19 +553,26 @@ class PartitionedGAT:
             torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
         gf = torch.empty_like(in_feat_loc)
         gc = torch.empty_like(attn_col_loc)
+        # (the chunks share gr_tab when partial grad_attn_row rows are summed: one stream then)
+        streams = self._chunk_streams(gf.device) if (local_gr is not None and self.mode == "halo") else None
         for s, (a, b, cptr, rind, n_vis, rptr, cind, perm) in enumerate(self.b_blocks):
-            self._wait(handles[s])
             # every chunk writes its own columns of grad_feat / grad_attn_col; its grad_attn_row
             # is a partial sum over the table rows it can see
             outs = (gf[a:b], None, gc[a:b])
             if local_gr is not None:
-                res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],
-                                                   in_feat_loc[a:b], attn_col_loc[a:b], grad_tab[:n_vis], out=outs,
-                                                   need_grad_attn_row=False)
+                with (torch.cuda.stream(streams[s % 2]) if streams is not None else contextlib.nullcontext()):
+                    self._wait(handles[s])
+                    res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],
+                                                       in_feat_loc[a:b], attn_col_loc[a:b], grad_tab[:n_vis], out=outs,
+                                                       need_grad_attn_row=False)
                 if res is not None:
                     continue
+                self._join_streams(streams, gf.device)
+                streams = None
                 local_gr = None             # (cannot happen for shapes the pair exists for; keep the old path whole)
                 gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
+            else:
+                self._wait(handles[s])
             res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],
                                                in_feat_loc[a:b], attn_col_loc[a:b], grad_tab[:n_vis], out=outs)
             if res is None:             # shape outside the packed kernels: unpack to four [rows,H] arrays
@@ -528,6 +580,7 @@ class PartitionedGAT:
                 res = self.ops.gat_backward(slope, rptr, cind, cptr, rind, perm, stat[1], stat[2], in_feat_loc[a:b],
                                             stat[0], attn_col_loc[a:b], grad_tab[:n_vis], stat[3], out=outs)
             gr_tab[:n_vis] += res[1]
+        self._join_streams(streams, gf.device)
         if local_gr is not None:
             gr = local_gr
         elif self.mode == "halo":
