@@ -506,7 +506,7 @@ int dgnn_gat_row_stats(int m, int h, int f, float negative_slope, const float *a
   hipStream_t st = (hipStream_t)stream;
   int rs = 1;
   while (rs < h * P.fv) rs <<= 1;
-  if (vec == 4 && rs <= 32) {
+  if (vec == 4 && rs <= env_int("DGNN_ROWSTAT_PACKED_MAX", 32)) {
     const long long rows_per_wave = (long long)(DGNN_WAVE / rs) * 4;
     hipLaunchKernelGGL(k_bwd_rowstat_packed, dim3(blocks_for_waves((m + rows_per_wave - 1) / rows_per_wave)),
                        dim3(DGNN_BLOCK), 0, st, P, rs);
@@ -606,7 +606,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     if (m > 0 && !packed) {
       int rs = 1;
       while (rs < h * P.fv) rs <<= 1;
-      if (vec == 4 && rs <= 32 && env_int("DGNN_ROWSTAT_PACKED", 1) != 0) {
+      if (vec == 4 && rs <= env_int("DGNN_ROWSTAT_PACKED_MAX", 32) && env_int("DGNN_ROWSTAT_PACKED", 1) != 0) {
         const long long rows_per_wave = (long long)(DGNN_WAVE / rs) * 4;
         hipLaunchKernelGGL(k_bwd_rowstat_packed, dim3(blocks_for_waves((m + rows_per_wave - 1) / rows_per_wave)),
                            dim3(DGNN_BLOCK), 0, st, P, rs);

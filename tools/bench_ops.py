@@ -103,7 +103,10 @@ def shapes(workload="products"):
     g = bench.build_graph(workload, dev)
     n, nnz = g["n"], g["nnz"]
     gen = torch.Generator(device=dev); gen.manual_seed(0)
-    for H, F in SHAPES:
+    todo = SHAPES           # DGNN_BENCH_SHAPES="1x44,1x48": another list
+    if os.environ.get("DGNN_BENCH_SHAPES"):
+        todo = tuple(tuple(int(v) for v in it.split("x")) for it in os.environ["DGNN_BENCH_SHAPES"].split(","))
+    for H, F in todo:
         x = torch.rand((n, H, F), device=dev, generator=gen) - 0.4
         ar = torch.rand((n, H), device=dev, generator=gen) - 0.6
         ac = torch.rand((n, H), device=dev, generator=gen) - 0.4
