@@ -20,6 +20,7 @@
 // gathered grad rows (a "U item" in front of the column's edges), so a switch of column never
 // stalls the pipeline.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "gather_fast.hpp"
 
@@ -689,25 +690,29 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P, int phase
     const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
     vec_t acc = V::zero();
     float dsum = 0.f;
-    // loads of FB pieces in flight together, sums in piece order
-    constexpr int FB = 8;
+    // loads of FB pieces in flight together, sums in piece order; the usual two pieces as a batch of two
     const bool want_d = P.grad_attn_col != nullptr;
-    for (int i0 = 0; i0 < cnt; i0 += FB) {
-      vec_t v[FB];
-      float d[FB];
+    auto merge = [&](auto fbc) {
+      constexpr int FB = decltype(fbc)::value;
+      for (int i0 = 0; i0 < cnt; i0 += FB) {
+        vec_t v[FB];
+        float d[FB];
 #pragma unroll
-      for (int j = 0; j < FB; ++j) {
-        const float *sp = slot_of(min(i0 + j, cnt - 1));
-        v[j] = *(const vec_t *)(sp + ln.off);
-        d[j] = want_d ? sp[P.HF + ln.head] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < FB; ++j)
-        if (i0 + j < cnt) {
-          vec_add<VEC>(acc, v[j]);
-          dsum += d[j];
+        for (int j = 0; j < FB; ++j) {
+          const float *sp = slot_of(min(i0 + j, cnt - 1));
+          v[j] = *(const vec_t *)(sp + ln.off);
+          d[j] = want_d ? sp[P.HF + ln.head] : 0.f;
         }
-    }
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+          if (i0 + j < cnt) {
+            vec_add<VEC>(acc, v[j]);
+            dsum += d[j];
+          }
+      }
+    };
+    if (cnt <= 2) merge(std::integral_constant<int, 2>{});
+    else merge(std::integral_constant<int, 8>{});
     if (phase == 0) {
       float *sp = slot_of(0);
       if (ln.active) {

@@ -21,6 +21,7 @@
 //   * a tiny fix-up kernel merges the partial slots of cut rows in a fixed order (online
 //              softmax merge), so results are deterministic.
 #pragma once
+#include <type_traits>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -1073,51 +1074,64 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
     const int fid = (active ? vs : 0) * vw;
     const int head = fid / P.F;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr int FB = 8;
+    // Pieces are loaded in batches whose loads are issued together, the arithmetic then runs over
+    // them in piece order (same sums as one piece at a time).  Nearly every cut row has two pieces:
+    // those take a batch of two (a batch of eight re-reads the last piece six times, and the
+    // address pipe, not the bytes, bounds this sweep); a list that fits one batch finds its
+    // maximum in the batch it accumulates from instead of in a walk of its own.
     if (MODE == MODE_GAT) {
-      // the loads of FB pieces are issued together, the arithmetic then runs over them in piece
-      // order (same sums as one piece at a time)
       float M = DGNN_NEG_INIT;
-      for (int i0 = 0; i0 < cnt; i0 += FB) {
-        float m[FB];
-#pragma unroll
-        for (int j = 0; j < FB; ++j) m[j] = slot_of(min(i0 + j, cnt - 1))[P.HF + head];
-#pragma unroll
-        for (int j = 0; j < FB; ++j) M = fmaxf(M, m[j]);
-      }
       float S = 0.f;
       // the negative-score aggregate and weight sum of the cut row ride the same batches (float4 rows only)
       const bool neg = P.out_neg != nullptr;
       float an = 0.f, nacc[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int i0 = 0; i0 < cnt; i0 += FB) {
-        float m[FB], sm[FB], sa[FB];
-        float4 v[FB], vn[FB];
+      auto merge = [&](auto fbc) {
+        constexpr int FB = decltype(fbc)::value;
+        const bool one = cnt <= FB;
+        if (!one)
+          for (int i0 = 0; i0 < cnt; i0 += FB) {
+            float m[FB];
 #pragma unroll
-        for (int j = 0; j < FB; ++j) {
-          const float *sp = slot_of(min(i0 + j, cnt - 1));
-          m[j] = sp[P.HF + head];
-          sm[j] = sp[P.HF + H + head];
-          if (vec4) v[j] = *(const float4 *)(sp + fid);
-          else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
-          if (neg) {
-            sa[j] = sp[P.HF + 2 * H + head];
-            vn[j] = *(const float4 *)(sp + P.slot_neg + fid);
+            for (int j = 0; j < FB; ++j) m[j] = slot_of(min(i0 + j, cnt - 1))[P.HF + head];
+#pragma unroll
+            for (int j = 0; j < FB; ++j) M = fmaxf(M, m[j]);
           }
-        }
+        for (int i0 = 0; i0 < cnt; i0 += FB) {
+          float m[FB], sm[FB], sa[FB];
+          float4 v[FB], vn[FB];
 #pragma unroll
-        for (int j = 0; j < FB; ++j)
-          if (i0 + j < cnt) {
-            const float fct = expf(m[j] - M);
-            S = fmaf(sm[j], fct, S);
-            acc[0] = fmaf(v[j].x, fct, acc[0]); acc[1] = fmaf(v[j].y, fct, acc[1]);
-            acc[2] = fmaf(v[j].z, fct, acc[2]); acc[3] = fmaf(v[j].w, fct, acc[3]);
+          for (int j = 0; j < FB; ++j) {
+            const float *sp = slot_of(min(i0 + j, cnt - 1));
+            m[j] = sp[P.HF + head];
+            sm[j] = sp[P.HF + H + head];
+            if (vec4) v[j] = *(const float4 *)(sp + fid);
+            else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
             if (neg) {
-              an = fmaf(sa[j], fct, an);
-              nacc[0] = fmaf(vn[j].x, fct, nacc[0]); nacc[1] = fmaf(vn[j].y, fct, nacc[1]);
-              nacc[2] = fmaf(vn[j].z, fct, nacc[2]); nacc[3] = fmaf(vn[j].w, fct, nacc[3]);
+              sa[j] = sp[P.HF + 2 * H + head];
+              vn[j] = *(const float4 *)(sp + P.slot_neg + fid);
             }
           }
-      }
+          if (one) {
+#pragma unroll
+            for (int j = 0; j < FB; ++j) M = fmaxf(M, m[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            if (i0 + j < cnt) {
+              const float fct = expf(m[j] - M);
+              S = fmaf(sm[j], fct, S);
+              acc[0] = fmaf(v[j].x, fct, acc[0]); acc[1] = fmaf(v[j].y, fct, acc[1]);
+              acc[2] = fmaf(v[j].z, fct, acc[2]); acc[3] = fmaf(v[j].w, fct, acc[3]);
+              if (neg) {
+                an = fmaf(sa[j], fct, an);
+                nacc[0] = fmaf(vn[j].x, fct, nacc[0]); nacc[1] = fmaf(vn[j].y, fct, nacc[1]);
+                nacc[2] = fmaf(vn[j].z, fct, nacc[2]); nacc[3] = fmaf(vn[j].w, fct, nacc[3]);
+              }
+            }
+        }
+      };
+      if (cnt <= 2) merge(std::integral_constant<int, 2>{});
+      else merge(std::integral_constant<int, 8>{});
       if (!final_pass) {
         // the partial triple replaces the first piece (every lane has consumed its loads: the values
         // stored depend on them)
@@ -1150,18 +1164,23 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
         }
       }
     } else {
-      for (int i0 = 0; i0 < cnt; i0 += FB) {
-        float4 v[FB];
+      auto merge = [&](auto fbc) {
+        constexpr int FB = decltype(fbc)::value;
+        for (int i0 = 0; i0 < cnt; i0 += FB) {
+          float4 v[FB];
 #pragma unroll
-        for (int j = 0; j < FB; ++j) {
-          const float *sp = slot_of(min(i0 + j, cnt - 1));
-          if (vec4) v[j] = *(const float4 *)(sp + fid);
-          else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
+          for (int j = 0; j < FB; ++j) {
+            const float *sp = slot_of(min(i0 + j, cnt - 1));
+            if (vec4) v[j] = *(const float4 *)(sp + fid);
+            else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            if (i0 + j < cnt) { acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w; }
         }
-#pragma unroll
-        for (int j = 0; j < FB; ++j)
-          if (i0 + j < cnt) { acc[0] += v[j].x; acc[1] += v[j].y; acc[2] += v[j].z; acc[3] += v[j].w; }
-      }
+      };
+      if (cnt <= 2) merge(std::integral_constant<int, 2>{});
+      else merge(std::integral_constant<int, 8>{});
       if (!final_pass) {
         float *sp = slot_of(0);
         if (active) {
