@@ -88,6 +88,17 @@ __device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdg
 
 // Make a value the compiler cannot prove uniform into an SGPR value (it IS uniform by construction).
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Logical workgroup id for L2 affinity.  Consecutive hardware workgroup ids are observed to land
+// on consecutive XCDs (MI355X_MICROARCH.md, workgroup dispatch), each with its own 4 MiB L2, so
+// neighbours in id order share nothing.  This bijection hands every residue class of ids mod 8
+// one contiguous range of logical ids: workgroups that read the same rows (one point cloud's
+// queries, one graph band) then share an L2.  A speed choice only -- any placement is correct.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned orig, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, x = orig & 7u;
+  const unsigned base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (orig >> 3);
+}
 __device__ __forceinline__ float uniform_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }

@@ -366,14 +366,17 @@ template <int KL, int NKK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL <= 32 ? 2 : 1, KL <= 32 ? 2 : 1)))
 void k_knn_mfma(int points, int pp, long long nq, const unsigned short *__restrict__ xh,
                 const unsigned short *__restrict__ xl, const float *__restrict__ nyk,
-                int *__restrict__ cand, float *__restrict__ key_last) {
+                int *__restrict__ cand, float *__restrict__ key_last, int xcd) {
   extern __shared__ __align__(16) float lds[];
   constexpr int DIMP = NKK * 16;
   constexpr int PER_WAVE = (KL * 32 * 2 > KNN_MQ * 64 * 2) ? KL * 32 * 2 : KNN_MQ * 64 * 2;   // floats
   const int wave = wave_in_block(), lane = lane_id();
   const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int q0 = uniform_i32((blockIdx.x * 4 + wave) * 32);
+  // a cloud's query blocks on one XCD: they all walk the same candidates (DGNN_KNN_XCD=0: launch order)
+  const unsigned lid = xcd ? xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y)
+                           : blockIdx.y * gridDim.x + blockIdx.x;
+  const int b = uniform_i32((int)(lid / gridDim.x)), bx = uniform_i32((int)(lid % gridDim.x));
+  const int q0 = uniform_i32((bx * 4 + wave) * 32);
   if (q0 >= points) return;                                  // no block-wide barrier below
   float *qd = lds + (size_t)wave * PER_WAVE;                 // [KNN_MQ][64] keys
   int *qi = (int *)(qd + KNN_MQ * 64);                       // [KNN_MQ][64] ids
@@ -533,14 +536,17 @@ template <int KL, int NKK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_knn_mfma_packed(int points, int pp, long long nq, const unsigned short *__restrict__ xh,
                        const unsigned short *__restrict__ xl, const float *__restrict__ nyk,
-                       int *__restrict__ cand, float *__restrict__ key_last) {
+                       int *__restrict__ cand, float *__restrict__ key_last, int xcd) {
   extern __shared__ __align__(16) float lds[];
   constexpr int DIMP = NKK * 16;
   constexpr int PER_WAVE = (KL * 32 > KNN_MQ * 64) ? KL * 32 : KNN_MQ * 64;        // words
   const int wave = wave_in_block(), lane = lane_id();
   const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int q0 = uniform_i32((blockIdx.x * 4 + wave) * 32);
+  // a cloud's query blocks on one XCD: they all walk the same candidates (DGNN_KNN_XCD=0: launch order)
+  const unsigned lid = xcd ? xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y)
+                           : blockIdx.y * gridDim.x + blockIdx.x;
+  const int b = uniform_i32((int)(lid / gridDim.x)), bx = uniform_i32((int)(lid % gridDim.x));
+  const int q0 = uniform_i32((bx * 4 + wave) * 32);
   if (q0 >= points) return;                                  // no block-wide barrier below
   unsigned *qv = (unsigned *)lds + (size_t)wave * PER_WAVE;  // [KNN_MQ][64] queued words
   const size_t base = (size_t)b * pp;
@@ -720,14 +726,18 @@ __global__ __launch_bounds__(256)
 void k_knn_rerank(int points, int pp, int dim, int k, int kl, long long nq, const float *__restrict__ x,
                   const float *__restrict__ nyk, const int *__restrict__ cand, float *__restrict__ key_last,
                   const int *__restrict__ cloud_bad, int *__restrict__ src_ind, int *__restrict__ redo_flags,
-                  int *__restrict__ block_flags, int *__restrict__ query_flags, int redo_max) {
+                  int *__restrict__ block_flags, int *__restrict__ query_flags, int redo_max, int xcd) {
   extern __shared__ __align__(16) float lds[];
-  const int lane = lane_id(), wave = wave_in_block(), b = blockIdx.y;
+  const int lane = lane_id(), wave = wave_in_block();
+  // as in the filter kernels: a cloud's blocks share an XCD's L2 (their candidate rows overlap)
+  const unsigned lid = xcd ? xcd_contiguous_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y)
+                           : blockIdx.y * gridDim.x + blockIdx.x;
+  const int b = uniform_i32((int)(lid / gridDim.x)), bx = uniform_i32((int)(lid % gridDim.x));
   float *tile = lds + (size_t)wave * 64 * KNN_RS;             // wave-private [64][KNN_RS]
   float *dl = lds + (size_t)4 * 64 * KNN_RS;                  // [kl][64] exact distances (+inf = no entry)
   int *il = (int *)(dl + (size_t)kl * 64);                    // [kl][64] ids
   float *dks = (float *)(il + (size_t)kl * 64);               // [64] k-th exact distance
-  const int i = blockIdx.x * 64 + lane;
+  const int i = bx * 64 + lane;
   const bool active = i < points;
   const float *xc = x + (size_t)b * points * dim;
   const long long gq = (long long)b * points + (active ? i : 0);
@@ -824,7 +834,7 @@ void k_knn_rerank(int points, int pp, int dim, int k, int kl, long long nq, cons
   }
   const int nbad = __popcll(__ballot(!safe));
   if (lane == 0) {
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t blk = (size_t)b * gridDim.x + bx;
     redo_flags[blk] = (nbad > 0 && nbad <= redo_max) ? 1 : 0;      // few: k_knn_redo, query by query
     block_flags[blk] = nbad > redo_max ? 1 : 0;                    // many (ties everywhere): k_knn
   }
@@ -993,7 +1003,7 @@ static int launch_knn_mfma_packed(int nkk, dim3 grid, hipStream_t st, int points
   if (nkk == N) {                                                                                          \
     const size_t lds = queue;                                                                              \
     hipLaunchKernelGGL((k_knn_mfma_packed<KL, N>), grid, dim3(256), lds, st, points, pp, nq, xh, xl, nyk,  \
-                       cand, key_last);                                                                    \
+                       cand, key_last, env_int("DGNN_KNN_XCD", 1));                                        \
     return DGNN_OK;                                                                                        \
   }
   DGNN_KNN_MFMA_CASE(2)
@@ -1011,7 +1021,7 @@ static int launch_knn_mfma(int nkk, dim3 grid, size_t lds, hipStream_t st, int p
   if (nkk == N) {                                                                                          \
     if (int rc = knn_allow_lds((const void *)k_knn_mfma<KL, N>, lds)) return rc;                           \
     hipLaunchKernelGGL((k_knn_mfma<KL, N>), grid, dim3(256), lds, st, points, pp, nq, xh, xl, nyk, cand,   \
-                       key_last);                                                                          \
+                       key_last, env_int("DGNN_KNN_XCD", 1));                                              \
     return DGNN_OK;                                                                                        \
   }
   DGNN_KNN_MFMA_CASE(2)
@@ -1031,7 +1041,8 @@ static int launch_knn_rerank(int batch, int points, int pp, int dim, int k, int 
   if (dim <= FCV) {                                                                                      \
     if (int rc = knn_allow_lds((const void *)k_knn_rerank<FCV>, lds)) return rc;                         \
     hipLaunchKernelGGL((k_knn_rerank<FCV>), grid, dim3(256), lds, st, points, pp, dim, k, kl, nq, x, nyk, cand, \
-                       key_last, bad, src_ind, rflags, flags, qflags, env_int("DGNN_KNN_REDO_MAX", KNN_REDO_MAX)); \
+                       key_last, bad, src_ind, rflags, flags, qflags, env_int("DGNN_KNN_REDO_MAX", KNN_REDO_MAX), \
+                       env_int("DGNN_KNN_XCD", 1));                                                      \
     DGNN_LAUNCH_CHECK();                                                                                 \
     return DGNN_OK;                                                                                      \
   }

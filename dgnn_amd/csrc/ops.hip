@@ -372,13 +372,24 @@ __global__ __launch_bounds__(DGNN_GBP_BLOCK) void k_gaussian_bwd_stage2(
 // candidate with the LARGEST BIT-REVERSED 5-bit tile position wins; padding lanes of the last
 // tile carry (-1e38, -1) and, holding position 31 (bit-reversal 31), win every tie; a later
 // tile replaces the running best on >= (:39).  max_val starts at -1e39 == -inf (:19).
+static inline int edgeconv_xcd() {
+  const char *e = getenv("DGNN_EDGECONV_XCD");
+  return e ? atoi(e) : 1;
+}
+static inline int edgeconv_vec4() {         // DGNN_EDGECONV_VEC4=0: the one-lane-per-column kernel (A/B runs)
+  const char *e = getenv("DGNN_EDGECONV_VEC4");
+  return e ? atoi(e) : 1;
+}
 __device__ __forceinline__ int bitrev5(int x) { return (int)(__brev((unsigned)x) >> 27); }
 
 __global__ __launch_bounds__(DGNN_BLOCK) void k_edgeconv_fwd(
     int m, int F, int k, const int *__restrict__ src_ind, const float *__restrict__ h_src,
     const float *__restrict__ h_dst, float *__restrict__ out_feat, float *__restrict__ idx_f32,
-    int *__restrict__ idx_i32) {
-  const int r = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wave_in_block());
+    int *__restrict__ idx_i32, int xcd) {
+  // points in id order are clouds in id order, and a point's neighbours lie in its own cloud:
+  // contiguous point ranges per XCD keep each cloud's rows in ONE L2 (DGNN_EDGECONV_XCD=0: launch order)
+  const unsigned lb_id = xcd ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int r = uniform_i32((int)lb_id * DGNN_WAVES_PER_BLOCK + wave_in_block());
   if (r >= m) return;
   const int lane = lane_id();
   const size_t lb = (size_t)r * k;
@@ -418,6 +429,77 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_edgeconv_fwd(
       out_feat[(size_t)r * F + fid] = max_val;
       idx_f32[(size_t)r * F + fid] = (float)max_id;
       if (idx_i32 != nullptr) idx_i32[(size_t)r * F + fid] = max_id;
+    }
+  }
+}
+
+// The same for rows of float4 slots (F % 4 == 0, 16-byte aligned tensors): a point takes LP lanes
+// (LP = slots per row rounded up to a power of two, at most 64), a wave 64 / LP points, and the
+// neighbour rows are loaded four at a time before the first compare.  The one-lane-per-column form
+// above keeps ONE 256-byte load in flight per wave and is bound by its latency (F = 64: 20
+// dependent round trips per point, 4.9 TB/s out of L2); here a wave issues 4 KiB per batch.
+// Candidates are visited in the same order with the same comparisons: identical results.
+struct EcBest { float bv; int bkey, bid; };
+__device__ __forceinline__ void ec_take(EcBest &b, float v, int key, int s) {
+  if (b.bkey < 0 || v > b.bv || (v == b.bv && key > b.bkey)) { b.bv = v; b.bkey = key; b.bid = s; }
+}
+__global__ __launch_bounds__(DGNN_BLOCK) void k_edgeconv_fwd4(
+    int m, int F, int k, int LP, const int *__restrict__ src_ind, const float *__restrict__ h_src,
+    const float *__restrict__ h_dst, float *__restrict__ out_feat, float *__restrict__ idx_f32,
+    int *__restrict__ idx_i32, int xcd) {
+  const unsigned lb_id = xcd ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int lane = lane_id();
+  const int G = DGNN_WAVE / LP;
+  const int gl = lane & (LP - 1), gbase = lane & ~(LP - 1);
+  const long long r = ((long long)lb_id * DGNN_WAVES_PER_BLOCK + wave_in_block()) * G + lane / LP;
+  const bool row_ok = r < m;
+  const size_t lb = (size_t)(row_ok ? r : 0) * k;
+  for (int fb = 0; fb < F; fb += 4 * LP) {
+    const int fid = fb + 4 * gl;
+    const bool live = row_ok && fid < F;
+    const float4 dv = live ? *(const float4 *)(h_dst + (size_t)r * F + fid) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float mv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int mi[4] = {-1, -1, -1, -1};
+    for (int t0 = 0; t0 < k; t0 += 32) {
+      const int cnt = min(32, k - t0);
+      // the group's lanes hold the tile's neighbour ids: position q in lane q % LP of register q / LP
+      int ids0 = 0, ids1 = 0;
+      if (row_ok && gl < cnt) ids0 = src_ind[lb + t0 + gl];
+      if (row_ok && LP < 32 && gl + LP < cnt) ids1 = src_ind[lb + t0 + gl + LP];
+      EcBest best[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { best[c].bv = 0.f; best[c].bkey = -1; best[c].bid = -1; }
+      constexpr int U = 4;
+      for (int q0 = 0; q0 < cnt; q0 += U) {
+        int sid[U];
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int q = min(q0 + u, cnt - 1);
+          sid[u] = __shfl(q < LP ? ids0 : ids1, gbase | (q & (LP - 1)), DGNN_WAVE);
+          x[u] = live ? *(const float4 *)(h_src + (size_t)sid[u] * F + fid) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (q0 + u < cnt) {
+            const int key = bitrev5(q0 + u);
+            ec_take(best[0], dv.x + x[u].x, key, sid[u]);
+            ec_take(best[1], dv.y + x[u].y, key, sid[u]);
+            ec_take(best[2], dv.z + x[u].z, key, sid[u]);
+            ec_take(best[3], dv.w + x[u].w, key, sid[u]);
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (cnt < 32 && -1e38f >= best[c].bv) { best[c].bv = -1e38f; best[c].bid = -1; }
+        if (best[c].bv >= mv[c]) { mv[c] = best[c].bv; mi[c] = best[c].bid; }
+      }
+    }
+    if (live) {
+      const size_t o = (size_t)r * F + fid;
+      *(float4 *)(out_feat + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *(float4 *)(idx_f32 + o) = make_float4((float)mi[0], (float)mi[1], (float)mi[2], (float)mi[3]);
+      if (idx_i32 != nullptr) *(int4 *)(idx_i32 + o) = make_int4(mi[0], mi[1], mi[2], mi[3]);
     }
   }
 }
@@ -480,26 +562,48 @@ __global__ __launch_bounds__(256) void k_edgeconv_bwd_gather(long long total, in
                                                              const int *__restrict__ row_ind,
                                                              const int *__restrict__ max_idx,
                                                              const float *__restrict__ grad_out,
-                                                             float *__restrict__ grad_src) {
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+                                                             float *__restrict__ grad_src, int xcd) {
+  // the rows that list s are points of s's own cloud: contiguous ranges of s per XCD (see k_edgeconv_fwd)
+  const unsigned lb_id = xcd ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+  for (long long t = lb_id * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
   const int s = (int)(t / slots), q = (int)(t - (long long)s * slots);
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
   int prev = -1;
-  for (int e = col_ptr[s]; e < col_ptr[s + 1]; ++e) {
-    const int r = row_ind[e];
-    if (r == prev) continue;                 // s listed twice by r: one contribution, as the scatter
-    prev = r;
-    const size_t at = (size_t)r * F + (size_t)q * VEC;
-    if (VEC == 4) {
-      const int4 id = *(const int4 *)(max_idx + at);
-      const float4 g = *(const float4 *)(grad_out + at);
-      acc[0] += id.x == s ? g.x : 0.f; acc[1 % VEC] += id.y == s ? g.y : 0.f;
-      acc[2 % VEC] += id.z == s ? g.z : 0.f; acc[3 % VEC] += id.w == s ? g.w : 0.f;
-    } else {
-      acc[0] += max_idx[at] == s ? grad_out[at] : 0.f;
+  // four listing rows per trip: their ids first, then their eight loads, then the sums in list order
+  // (one row per trip was a chain of two dependent round trips per neighbour)
+  constexpr int U = 4;
+  const int e1 = col_ptr[s + 1];
+  for (int e = col_ptr[s]; e < e1; e += U) {
+    int rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) rr[u] = row_ind[min(e + u, e1 - 1)];
+    int4 id[U];
+    float4 g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t at = (size_t)rr[u] * F + (size_t)q * VEC;
+      if (VEC == 4) {
+        id[u] = *(const int4 *)(max_idx + at);
+        g[u] = *(const float4 *)(grad_out + at);
+      } else {
+        id[u] = make_int4(max_idx[at], -1, -1, -1);
+        g[u] = make_float4(grad_out[at], 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u >= e1) break;
+      const bool again = rr[u] == prev;      // s listed twice by r: one contribution, as the scatter
+      prev = rr[u];
+      if (again) continue;
+      acc[0] += id[u].x == s ? g[u].x : 0.f;
+      if (VEC == 4) {
+        acc[1 % VEC] += id[u].y == s ? g[u].y : 0.f;
+        acc[2 % VEC] += id[u].z == s ? g[u].z : 0.f; acc[3 % VEC] += id[u].w == s ? g[u].w : 0.f;
+      }
     }
   }
   const size_t o = (size_t)s * F + (size_t)q * VEC;
@@ -633,9 +737,20 @@ int dgnn_edgeconv_forward(int m, int f, int k, const int *src_ind, const float *
   if (m < 0 || f <= 0 || k < 0) return DGNN_ERR_BAD_ARG;
   if (m == 0) return DGNN_OK;
   if (!h_src || !h_dst || !out_feat || !max_idx_f32 || (k > 0 && !src_ind)) return DGNN_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_edgeconv_fwd, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
-                     (hipStream_t)stream, m, f, k, src_ind, h_src, h_dst, out_feat, max_idx_f32,
-                     max_idx_i32);
+  const bool al16 = ((((uintptr_t)h_src) | ((uintptr_t)h_dst) | ((uintptr_t)out_feat) | ((uintptr_t)max_idx_f32) |
+                      ((uintptr_t)max_idx_i32)) & 15u) == 0;
+  if (f % 4 == 0 && al16 && edgeconv_vec4()) {
+    int lp = 16;                 // at least 16 lanes per point: two registers then hold a 32-neighbour tile's ids
+    while (lp < f / 4 && lp < DGNN_WAVE) lp <<= 1;
+    const long long waves = ((long long)m + DGNN_WAVE / lp - 1) / (DGNN_WAVE / lp);
+    hipLaunchKernelGGL(k_edgeconv_fwd4, dim3(blocks_for_waves(waves)), dim3(DGNN_BLOCK), 0,
+                       (hipStream_t)stream, m, f, k, lp, src_ind, h_src, h_dst, out_feat, max_idx_f32,
+                       max_idx_i32, edgeconv_xcd());
+  } else {
+    hipLaunchKernelGGL(k_edgeconv_fwd, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
+                       (hipStream_t)stream, m, f, k, src_ind, h_src, h_dst, out_feat, max_idx_f32,
+                       max_idx_i32, edgeconv_xcd());
+  }
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }
@@ -689,10 +804,10 @@ int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const in
   const long long total = (long long)m * slots;
   if (vec4)
     hipLaunchKernelGGL(k_edgeconv_bwd_gather<4>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
-                       col_ptr, row_ind, max_idx, grad_out, grad_src);
+                       col_ptr, row_ind, max_idx, grad_out, grad_src, edgeconv_xcd());
   else
     hipLaunchKernelGGL(k_edgeconv_bwd_gather<1>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
-                       col_ptr, row_ind, max_idx, grad_out, grad_src);
+                       col_ptr, row_ind, max_idx, grad_out, grad_src, edgeconv_xcd());
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }

@@ -44,10 +44,11 @@ def edgeconv(batch=32, pts=2048, k=20):
         out, idx_f, idx_i = fe.edgeconv_forward(k, src, hs, hd, return_int_idx=True)
         tf = timeit(lambda: fe.edgeconv_forward(k, src, hs, hd, return_int_idx=True))
         tb = timeit(lambda: fe.edgeconv_backward(go, idx_i))
+        td = timeit(lambda: fe.edgeconv_backward(go, idx_i, src))      # deterministic form (the autograd operator's)
         bf = m * (4 * k + 4 * k * f + 4 * f + 12 * f)
         bb = m * (4 * f + 4 * f + 8 * f + 4 * f)
         print(json.dumps({"op": "edgeconv", "m": m, "k": k, "f": f, "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4),
-                          "fwd_GBps": round(bf / tf / 1e6, 1), "bwd_GBps": round(bb / tb / 1e6, 1)}), flush=True)
+                          "bwd_det_ms": round(td, 4), "fwd_GBps": round(bf / tf / 1e6, 1), "bwd_GBps": round(bb / tb / 1e6, 1)}), flush=True)
 
 
 def knn(batch=32, pts=2048, k=20):
