@@ -320,8 +320,45 @@ __device__ __forceinline__ unsigned short bf16_rne(float v) {        // finite o
   return (unsigned short)(u >> 16);
 }
 
+// Distances do not change when a cloud is shifted, the filter's slack c (nx + ny) does: feature
+// clouds (after an activation every coordinate is positive) sit far from the origin compared with
+// their neighbour distances, and the bound then certifies little (the DGCNN layers at 128 dims spent
+// as long in k_knn_redo as in the filter).  The filter therefore works on x' = fl(x - mu) with mu an
+// average of the cloud (ANY mu is valid; about 64 points at a fixed stride are averaged).  The exact
+// chain keeps the caller's x.  What the rounding of the subtraction adds: x'_i - x'_j differs from
+// x_i - x_j by at most 2^-24 (|x'_i| + |x'_j|) per vector, so |d - d'| <= 2^-22 (nx' + ny'): three
+// orders of magnitude inside the spare factor of c.
+constexpr int KNN_CENTER_SAMPLE = 64;
+__global__ __launch_bounds__(256) void k_knn_center(int points, int dim, int dimp, const float *__restrict__ x,
+                                                    float *__restrict__ mean) {
+  __shared__ float part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int f = tid % dimp, rp = tid / dimp, rows_par = 256 / dimp;     // dimp is 32, 64 or 128
+  const int stride = points > KNN_CENTER_SAMPLE ? points / KNN_CENTER_SAMPLE : 1;
+  const int ns = (points + stride - 1) / stride;                        // sampled points
+  const float *xc = x + (size_t)b * points * dim;
+  float s = 0.f;
+  if (f < dim) {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};                                 // four loads in flight
+    int i = rp;
+    for (; i + 3 * rows_par < ns; i += 4 * rows_par) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += xc[(size_t)(i + u * rows_par) * stride * dim + f];
+    }
+    for (; i < ns; i += rows_par) s4[0] += xc[(size_t)i * stride * dim + f];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (rp == 0) {
+    for (int q = 1; q < rows_par; ++q) s += part[q * dimp + f];
+    mean[(size_t)b * dimp + f] = f < dim ? s / (float)ns : 0.f;
+  }
+}
+
 // one thread per (padded point, group of 8 dims); the thread of group 0 also writes nyk
 __global__ void k_knn_split(int points, int pp, int dim, int dimp, const float *__restrict__ x,
+                            const float *__restrict__ mean,
                             unsigned short *__restrict__ xh, unsigned short *__restrict__ xl,
                             float *__restrict__ nyk, int *__restrict__ cloud_bad) {
   const int groups = dimp >> 3;
@@ -331,10 +368,12 @@ __global__ void k_knn_split(int points, int pp, int dim, int dimp, const float *
   const int j = (int)(t / groups), g = (int)(t - (long long)j * groups);
   const float *row = x + ((size_t)b * points + (j < points ? j : 0)) * dim;
   unsigned short hi[8], lo[8];
+  float vv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int f = g * 8 + e;
-    const float v = (j < points && f < dim) ? row[f] : 0.f;
+    const float v = (j < points && f < dim) ? row[f] - (mean != nullptr ? mean[(size_t)b * dimp + f] : 0.f) : 0.f;
+    vv[e] = v;
     hi[e] = bf16_rne(v);
     lo[e] = bf16_rne(v - __uint_as_float((unsigned)hi[e] << 16));
   }
@@ -346,11 +385,7 @@ __global__ void k_knn_split(int points, int pp, int dim, int dimp, const float *
   // |x|^2: every thread squares its 8 dims, the row's threads (4, 8 or 16 consecutive lanes) add up
   float part = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int f = g * 8 + e;
-    const float v = (j < points && f < dim) ? row[f] : 0.f;
-    part = fmaf(v, v, part);
-  }
+  for (int e = 0; e < 8; ++e) part = fmaf(vv[e], vv[e], part);
   for (int off = 1; off < groups; off <<= 1) part += __shfl_xor(part, off, 64);
   if (g == 0) {
     float ny = __builtin_inff();
@@ -954,7 +989,7 @@ void k_knn_redo(int points, int dim, int k, const float *__restrict__ x, const i
 }
 
 struct KnnWs {
-  size_t off_xh, off_xl, off_nyk, off_cand, off_key, off_bad, off_flags, off_qflags, off_rflags, total;
+  size_t off_xh, off_xl, off_nyk, off_cand, off_key, off_bad, off_flags, off_qflags, off_rflags, off_mean, total;
   int pp, dimp, kl;
 };
 // list length of the filter: k + at least 4 spare candidates.  Cost grows with KL^2 (accepted
@@ -978,6 +1013,7 @@ static KnnWs knn_ws_layout(int batch, int points, int dim, int k) {
   w.off_flags = seg((size_t)batch * ((points + 63) / 64) * 4);
   w.off_qflags = seg(nq * 4);
   w.off_rflags = seg((size_t)batch * ((points + 63) / 64) * 4);
+  w.off_mean = seg((size_t)batch * w.dimp * 4);
   w.total = o;
   return w;
 }
@@ -1076,9 +1112,14 @@ static int knn_filtered(int batch, int points, int dim, int k, const float *x, i
   const long long nq = (long long)batch * points;
   if (hipError_t e = hipMemsetAsync(bad, 0, (size_t)batch * 4, st); e != hipSuccess) return (int)e;
   {
+    float *mean = env_int("DGNN_KNN_CENTER", 1) != 0 ? (float *)(ws + w.off_mean) : nullptr;
+    if (mean != nullptr) {
+      hipLaunchKernelGGL(k_knn_center, dim3((unsigned)batch), dim3(256), 0, st, points, dim, w.dimp, x, mean);
+      DGNN_LAUNCH_CHECK();
+    }
     const long long threads = (long long)w.pp * (w.dimp / 8);
     hipLaunchKernelGGL(k_knn_split, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, st,
-                       points, w.pp, dim, w.dimp, x, xh, xl, nyk, bad);
+                       points, w.pp, dim, w.dimp, x, (const float *)mean, xh, xl, nyk, bad);
     DGNN_LAUNCH_CHECK();
   }
   {

@@ -828,14 +828,16 @@ def test_knn_graph_with_nan_and_inf_points_stays_in_range():
     (2, 200, 100, 24, "normal"), (2, 150, 70, 28, "normal"), (1, 500, 128, 40, "normal"), (1, 300, 90, 56, "normal"),
     (1, 2048, 64, 20, "normal"), (2, 300, 64, 20, "quantised"), (2, 260, 40, 20, "duplicates"),
     (2, 300, 64, 20, "clustered"), (2, 200, 64, 12, "nonfinite"), (2, 300, 32, 20, "huge"), (2, 300, 48, 20, "tiny"),
-    (1, 4500, 20, 5, "normal")])
+    (1, 4500, 20, 5, "normal"), (2, 600, 64, 20, "features"), (1, 700, 128, 20, "features"),
+    (2, 300, 64, 20, "two_blobs")])
 def test_knn_filtered_path_is_bit_exact(b, p, dim, k, kind, monkeypatch):
     """The matrix-core candidate filter in front of the exact chain (csrc/knn.hip, dims 17 .. 128)
     is forced on for small problems: ids bit-exact against the oracle's exhaustive search on
     continuous data (the filter certifies nearly every query), on data made of exact ties and
     duplicates (it certifies nothing: every query goes back to the exhaustive chain), on tight
     clusters far from the origin (norms >> distances: the certificate's margin decides), on
-    non-finite points and at the ends of the float32 range."""
+    feature-like clouds (every coordinate positive) with and without the shift to the cloud's average,
+    on non-finite points and at the ends of the float32 range."""
     from dgnn_amd.native.knn import knn_graph
     monkeypatch.setenv("DGNN_KNN_FILTER_MIN_WAVES", "1")
     rng = np.random.default_rng(b * 1000 + p + dim)
@@ -850,6 +852,11 @@ def test_knn_filtered_path_is_bit_exact(b, p, dim, k, kind, monkeypatch):
         x[0, 3] = np.nan
         x[0, 7, 5] = np.inf
         x[1, :150] = np.inf
+    elif kind == "features":        # what an activation leaves: positive coordinates, the cloud far from 0
+        x = x + 1.0
+        x = (np.where(x > 0, x, 0.2 * x) + 0.5).astype(np.float32)
+    elif kind == "two_blobs":       # the cloud's average lies between two distant groups
+        x[:, ::2] += 50.0
     elif kind == "huge":
         x = (x * 1e18).astype(np.float32)
     elif kind == "tiny":
@@ -868,6 +875,10 @@ def test_knn_filtered_path_is_bit_exact(b, p, dim, k, kind, monkeypatch):
     # clouds of at most 2048 points keep (bound, index) packed in one word per list entry; the
     # (key, id) form that larger clouds use gives the same ids
     monkeypatch.setenv("DGNN_KNN_PACKED", "0")
+    assert np.array_equal(host(knn_graph(dev(x), k)), want)
+    # the filter on the caller's coordinates instead of the cloud shifted to its average
+    monkeypatch.setenv("DGNN_KNN_PACKED", "1")
+    monkeypatch.setenv("DGNN_KNN_CENTER", "0")
     assert np.array_equal(host(knn_graph(dev(x), k)), want)
 
 
