@@ -1,10 +1,6 @@
 #!/bin/bash
 set -e -o pipefail
-mkdir -p gpurun_out/r2h
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q -k "knn" --timeout 300 --timeout-method thread 2>&1 | tail -n 3
-for data in gauss features; do
-  echo "== data=$data" | tee -a gpurun_out/r2h/knn_center2.txt
-  DGNN_KNN_BENCH_DATA=$data timeout -k 10 300 python tools/knn_bench.py 2>&1 | grep '^{' | tee -a gpurun_out/r2h/knn_center2.txt
-done
-timeout -k 10 300 python examples/train_edgeconv.py --n-epochs 20 2>&1 | tail -1
-timeout -k 10 300 python examples/train_edgeconv.py --n-epochs 20 --batch-size 64 --num-points 1024 --k 40 2>&1 | tail -1
+out=$GRAFT_REPO_ROOT/gpurun_out/r2h/ex_gmm; mkdir -p $out
+export TMPDIR=/tmp; cd /tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/examples/train_gmmconv.py --dataset reddit --n-epochs 10 > $out/trace.log 2>&1
+grep -v "^W\|^E" $out/trace.log | tail -3 | cut -c1-300
