@@ -7,6 +7,8 @@ The anchor is the oracle's float64 restatement; the oracle's literal float32 res
 the reference kernels is held to the same tolerance in tests/test_oracle.py, so HIP and the
 reference's own arithmetic sit in the same band around the exact value.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +22,10 @@ GRAPHS = named_graphs()
 GRAPHS["rmat4k"] = rmat_graph(12, 4000, 60000, 7)      # hubs: rows/columns with 1000+ entries
 
 DEV = "cuda:0"
+
+# DGNN_FUZZ_EXTRA=N: N more seeds for the degree-pattern fuzz tests (and N/4 for the hub fuzz), for a
+# longer hunt after a kernel change; the committed suite runs the base seeds only.
+FUZZ_EXTRA = int(os.environ.get("DGNN_FUZZ_EXTRA", "0"))
 
 
 def dev(a):
@@ -202,7 +208,7 @@ def test_gat_forward_short_rows_batched_four_per_pass_keeps_every_bit(nat, name,
             assert torch.equal(a, b), what
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + FUZZ_EXTRA))
 def test_gat_fuzz_degree_patterns_against_the_oracle(nat, seed, monkeypatch):
     """Random degree sequences aimed at the row logic of the neighbour-grouped kernels -- runs of short
     rows (the four-rows-per-pass softmax phase), empty rows between them, rows of exactly 16 / 17 /
@@ -244,6 +250,69 @@ def test_gat_fuzz_degree_patterns_against_the_oracle(nat, seed, monkeypatch):
     assert_close(host(got[0]), gf64, "fuzz: grad_feat", mass=m_gf)
     assert_close(host(got[1]), gr64, "fuzz: grad_attn_row", mass=m_gr)
     assert_close(host(got[2]), gc64, "fuzz: grad_attn_col", mass=m_gc)
+
+
+@pytest.mark.parametrize("seed", range(10 + FUZZ_EXTRA // 4))
+def test_gat_fuzz_hub_rows_and_columns_merged_in_two_levels(nat, seed, monkeypatch):
+    """Rows and columns cut into MORE than 16 pieces take the two-level merge of the fixup kernels
+    (DGNN_FIX_C pieces per first-level wave): hub rows and hub columns of 17 ... ~130 pieces at small
+    group sizes -- piece counts just above 16, at multiples of 16 and one past them, a hub next to
+    another hub, a hub as the last row -- forward (with the pair) and backward against the float64
+    oracle."""
+    from util import graph_from_edges
+    rng = np.random.default_rng(7000 + seed)
+    fl, bl = [16, 16, 32, 16, 64][seed % 5], 64
+    n = int(rng.integers(1100, 2100))
+    dst, src = [], []
+    # short rows everywhere
+    for r in range(n):
+        d = int(rng.integers(0, 6))
+        dst += [r] * d
+        src += list(rng.choice(n, size=d, replace=False))
+    # hub rows: piece counts around the two-level thresholds (pieces ~ degree / group size)
+    hubs = {0: [17, 16, 33][seed % 3] * fl + int(rng.integers(-3, 4)), n - 1: 48 * fl + 5,
+            n // 2: 31 * fl, n // 2 + 1: 32 * fl + 1}
+    for r, d in hubs.items():
+        d = min(n, max(1, d))
+        dst += [r] * d
+        src += list(rng.choice(n, size=d, replace=False))
+    # hub columns: many rows list the same source (the backward's cut columns)
+    for c, cnt in ((3, 17 * bl + int(rng.integers(-2, 3))), (n - 2, min(n, 33 * bl)), (n // 3, 16 * bl + 1)):
+        rows = rng.choice(n, size=min(n, cnt), replace=False)
+        dst += list(rows)
+        src += [c] * len(rows)
+    # graph_from_edges keeps one copy of a repeated (dst, src) pair
+    g = graph_from_edges(n, dst, src)
+    h, f = [(4, 64), (1, 64), (4, 16), (8, 8), (2, 32)][seed % 5]
+    p = 0.5 if seed % 2 else 0.0
+    monkeypatch.setenv("DGNN_FWD_L", str(fl))
+    monkeypatch.setenv("DGNN_BWD_L", str(bl))
+    slope = 0.2
+    in_feat, attn_row, attn_col, grad = gat_inputs(n, h, f, seed=seed)
+    mask = rng.random((g["nnz"], h), dtype=np.float32) if p > 0 else None
+    G = gdev(g)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    dm = dev(mask) if mask is not None else None
+    out, emax, esum, emask, out_neg, a_neg = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], slope, x, p,
+                                                                    edge_mask=dm, neg=True)
+    o64, emax64, esum64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope, in_feat, p, mask)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p)
+    assert_close(host(out), o64, "hub fuzz: out_feat", mass=m_out)
+    nonempty = np.diff(g["row_ptr"]) > 0
+    assert_close(host(emax)[nonempty], emax64[nonempty], "hub fuzz: edge_max")
+    assert_close(host(esum), esum64, "hub fuzz: edge_sum", mass=esum64)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(slope, p, g["row_ptr"], g["col_ind"], mask, in_feat, attn_row, attn_col, grad)
+    got = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                  emax, esum, emask, x, ar, ac, go, out_feat=out, out_neg=out_neg, a_neg=a_neg)
+    assert_close(host(got[0]), gf64, "hub fuzz: grad_feat", mass=m_gf)
+    assert_close(host(got[1]), gr64, "hub fuzz: grad_attn_row", mass=m_gr)
+    assert_close(host(got[2]), gc64, "hub fuzz: grad_attn_col", mass=m_gc)
+    # the backward without the pair (edge gradients + row sums) over the same cut columns
+    got2 = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                   emax, esum, emask, x, ar, ac, go, out_feat=out)
+    assert_close(host(got2[0]), gf64, "hub fuzz: grad_feat (no pair)", mass=m_gf)
+    assert_close(host(got2[1]), gr64, "hub fuzz: grad_attn_row (no pair)", mass=m_gr)
+    assert_close(host(got2[2]), gc64, "hub fuzz: grad_attn_col (no pair)", mass=m_gc)
 
 
 def test_gat_negative_score_pair_shapes_without_it(nat):

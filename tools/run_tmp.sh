@@ -1,6 +1,4 @@
 #!/bin/bash
 set -e -o pipefail
-out=$GRAFT_REPO_ROOT/gpurun_out/r2h/ex_gmm; mkdir -p $out
-export TMPDIR=/tmp; cd /tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/examples/train_gmmconv.py --dataset reddit --n-epochs 10 > $out/trace.log 2>&1
-grep -v "^W\|^E" $out/trace.log | tail -3 | cut -c1-300
+mkdir -p gpurun_out/r2h
+DGNN_FUZZ_EXTRA=600 timeout -k 10 900 python -u -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuzz" --timeout 300 --timeout-method thread 2>&1 | tee gpurun_out/r2h/fuzz_long.log | tail -n 12
