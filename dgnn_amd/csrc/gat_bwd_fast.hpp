@@ -33,6 +33,7 @@ namespace dgnn {
 struct BwdParams {
   int n, m, nnz, H, F, HF, L, T;
   int steady;          // narrow rows: unguarded steady-state gather stream (STEADY instantiation)
+  int fv_const;        // 0: the packed stream keeps run-time lane widths (DGNN_BWD_PACK_CONST=0, A/B runs)
   int pack_s;          // > 0: lanes per row of the PACKED stream (H * fv <= 32 lanes: 64 / pack_s edges of a
                        // column per load step), see the stream phase
   int vec;             // floats per lane load: 4 (F % 4 == 0, 16-byte aligned rows) or 1
@@ -386,14 +387,25 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     bool took_steady = false;
     if constexpr (STEADY && VEC == 4) {
       if (packed) {
-        // ---- packed stream (H * fv <= 32 lanes per row): the lanes form G = 64 / S groups; an
+        // ---- packed stream (H * fv <= 16 lanes per row): the lanes form G = 64 / S groups; an
         // edge step gathers the grad rows of G consecutive entries of ONE column (group g: entry
         // p0 + g), each group keeps its own partial sums, and the column's last step adds them
         // across groups.  The column's own row (U step) is loaded by every group alike.
+        //
+        // The lanes per head (fv) and per row (S = max(4, HC * fv): heads are padded to HC) are
+        // compile-time constants of the runner: with run-time widths the per-entry dot reduction
+        // was a chain of six wave-uniform branches and the column-end sum a loop of shuffles --
+        // 11 scalar instructions per EDGE at 1 x 64 and K = 3 x 16, as many cycles as the vector work
+        // (profiles/r2h_pmc_sq_gmmsum16_reddit.csv).  FVC = 0 keeps the run-time widths (shapes
+        // whose row width is not max(4, HC * fv)).
         took_steady = true;
-        const int S = P.pack_s;
+        auto run_packed = [&](auto fvc) {
+        constexpr int FVC = decltype(fvc)::value;
+        constexpr int SC = FVC == 0 ? 0 : (HC * FVC > 4 ? HC * FVC : 4);
+        const int fv = FVC == 0 ? P.fv : FVC;
+        const int S = FVC == 0 ? P.pack_s : SC;
         const int g = lane / S, sl = lane % S;
-        const int hd = sl / P.fv, qq = sl % P.fv;
+        const int hd = sl / fv, qq = sl % fv;
         const bool act = hd < H && qq * 4 < P.F;
         const int phead = act ? hd : 0;
         const size_t poff = act ? (size_t)phead * P.F + (size_t)qq * 4 : 0;
@@ -423,18 +435,36 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           const float w = live ? fabsf(wb.x) : 0.f;
           const float slp = (__float_as_uint(wb.x) & 0x80000000u) ? P.slope : 1.f;
           float dot = act ? vec_dot<4>(x, u) : 0.f;
-          dot = group_reduce(dot, P.fv, OpSum());
+          if constexpr (FVC == 0) {
+            dot = group_reduce(dot, fv, OpSum());
+          } else {               // at most 16 lanes per head here: the four DPP steps, no branch
+            if constexpr (FVC >= 2) dot += dpp_f32<DGNN_DPP_QUAD_XOR1>(dot);
+            if constexpr (FVC >= 4) dot += dpp_f32<DGNN_DPP_QUAD_XOR2>(dot);
+            if constexpr (FVC >= 8) dot += dpp_f32<DGNN_DPP_ROW_HALF_MIRROR>(dot);
+            if constexpr (FVC >= 16) dot += dpp_f32<DGNN_DPP_ROW_MIRROR>(dot);
+          }
           const float d = live ? ((BMODE == BWD_GMM) ? dot : fmaf(slp * w, dot, -wb.y)) : 0.f;
           V::fma(acc, w, x);
           dsum += d;
           if (pleader && live) cp->y = d;
           if (it & DGNN_PACK_END) {
-            for (int off = S; off < DGNN_WAVE; off <<= 1) {
-              acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
-              acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
-              acc.z += __shfl_xor(acc.z, off, DGNN_WAVE);
-              acc.w += __shfl_xor(acc.w, off, DGNN_WAVE);
-              dsum += __shfl_xor(dsum, off, DGNN_WAVE);
+            if constexpr (FVC == 0) {
+              for (int off = S; off < DGNN_WAVE; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
+                acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
+                acc.z += __shfl_xor(acc.z, off, DGNN_WAVE);
+                acc.w += __shfl_xor(acc.w, off, DGNN_WAVE);
+                dsum += __shfl_xor(dsum, off, DGNN_WAVE);
+              }
+            } else {
+#pragma unroll
+              for (int off = SC; off < DGNN_WAVE; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
+                acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
+                acc.z += __shfl_xor(acc.z, off, DGNN_WAVE);
+                acc.w += __shfl_xor(acc.w, off, DGNN_WAVE);
+                dsum += __shfl_xor(dsum, off, DGNN_WAVE);
+              }
             }
             const int dst = uniform_i32(dq[k]);
             if (g == 0) {
@@ -483,6 +513,17 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
             consume(x, j);
           }
         }
+        };   // run_packed
+        const int want_s = HC * P.fv > 4 ? HC * P.fv : 4;
+        const bool spec = P.pack_s == want_s && P.fv_const != 0;
+        bool ran = false;
+        if (spec) {
+          if constexpr (HC * 16 <= 16) { if (!ran && P.fv == 16) { run_packed(std::integral_constant<int, 16>{}); ran = true; } }
+          if constexpr (HC * 8 <= 16)  { if (!ran && P.fv == 8)  { run_packed(std::integral_constant<int, 8>{});  ran = true; } }
+          if constexpr (HC * 4 <= 16)  { if (!ran && P.fv == 4)  { run_packed(std::integral_constant<int, 4>{});  ran = true; } }
+          if constexpr (HC * 2 <= 16)  { if (!ran && P.fv == 2)  { run_packed(std::integral_constant<int, 2>{});  ran = true; } }
+        }
+        if (!ran) run_packed(std::integral_constant<int, 0>{});
       }
     }
     if constexpr (STEADY) {

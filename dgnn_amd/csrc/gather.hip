@@ -592,6 +592,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.hpp = DGNN_WAVE / P.fv;
     P.steady = (vec == 4 && h * f / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
     P.pack_s = bwd_pack_lanes(P.steady != 0, h, P.fv);
+    P.fv_const = env_int("DGNN_BWD_PACK_CONST", 1);
     const int hc = bwd_heads_padded(h);
     P.attn_drop = attn_drop; P.slope = negative_slope;
     P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
@@ -888,6 +889,7 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
   P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
   P.steady = (vec == 4 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
   P.pack_s = bwd_pack_lanes(P.steady != 0, kernels, P.fv);
+  P.fv_const = env_int("DGNN_BWD_PACK_CONST", 1);
   P.slot_stride = (int)align_up((size_t)kernels * embed + kernels, 4);
   P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
   P.in_feat = node_feat; P.grad = grad; P.grad_feat = grad_node_feat; P.grad_attn_col = nullptr;
