@@ -183,4 +183,10 @@ static inline int blocks_for_waves(long long n_waves) {
   return (int)((n_waves + DGNN_WAVES_PER_BLOCK - 1) / DGNN_WAVES_PER_BLOCK);
 }
 
+// convert.hip: CSC form (col_ptr [m+1], row_ind [m*k], rows ascending inside a column) of m lists of
+// exactly k column ids each
+int transpose_uniform_lists(int m, int k, const int *col_ind, int *col_ptr, int *row_ind, void *workspace,
+                            size_t workspace_bytes, hipStream_t st);
+size_t transpose_uniform_lists_workspace_bytes(int m, int k);
+
 }  // namespace dgnn

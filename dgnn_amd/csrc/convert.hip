@@ -55,6 +55,14 @@ __global__ void k_gather_rows(int nnz, const int *__restrict__ permute, const in
     row_ind[i] = rows_csr[permute[i]];
 }
 
+// row_ind[i] = permute[i] / k: the row of a CSR position when every row holds exactly k entries
+// (k-NN lists): no row_ptr, no expanded row array.
+__global__ void k_rows_uniform(int nnz, int k, const int *__restrict__ permute, int *__restrict__ row_ind) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz;
+       i += (long long)gridDim.x * blockDim.x)
+    row_ind[i] = permute[i] / k;
+}
+
 static inline int grid_1d(long long total, int block) {
   long long g = (total + block - 1) / block;
   const long long cap = 256LL * 32;
@@ -74,6 +82,47 @@ static hipError_t sort_temp_bytes(int nnz, int bits, size_t *bytes) {
   return rocprim::radix_sort_pairs(nullptr, *bytes, (const int *)nullptr, (int *)nullptr,
                                    rocprim::counting_iterator<int>(0), (int *)nullptr,
                                    (size_t)nnz, 0, bits, (hipStream_t)0);
+}
+
+// Transpose of m lists of exactly k column ids each (the k-NN lists in front of EdgeConv): col_ptr /
+// row_ind of the CSC form, rows ascending inside a column.  dgnn_csr2csc without the row_ptr
+// array, the expanded rows and the permutation as an output: sort, pointer search, one divide
+// per entry.  Workspace: dgnn_csr2csc_workspace_bytes(m, m, m * k) + 4 * m * k bytes.
+int transpose_uniform_lists(int m, int k, const int *col_ind, int *col_ptr, int *row_ind, void *workspace,
+                            size_t workspace_bytes, hipStream_t st) {
+  const long long nnz64 = (long long)m * k;
+  if (m < 0 || k < 0 || nnz64 > 0x7fffffffLL || !col_ptr) return DGNN_ERR_BAD_ARG;
+  const int nnz = (int)nnz64;
+  if (nnz == 0) {
+    hipError_t e = hipMemsetAsync(col_ptr, 0, sizeof(int) * ((size_t)m + 1), st);
+    return e == hipSuccess ? DGNN_OK : (int)e;
+  }
+  if (!col_ind || !row_ind) return DGNN_ERR_BAD_ARG;
+  const int bits = key_bits(m);
+  size_t temp = 0;
+  hipError_t e = sort_temp_bytes(nnz, bits, &temp);
+  if (e != hipSuccess) return (int)e;
+  const size_t keys_bytes = align_up(sizeof(int) * (size_t)nnz, 256);
+  if (!workspace || workspace_bytes < 2 * keys_bytes + align_up(temp, 256)) return DGNN_ERR_WORKSPACE;
+  int *sorted_keys = (int *)workspace;
+  int *permute = (int *)((char *)workspace + keys_bytes);
+  void *sort_tmp = (char *)workspace + 2 * keys_bytes;
+  e = rocprim::radix_sort_pairs(sort_tmp, temp, col_ind, sorted_keys, rocprim::counting_iterator<int>(0), permute,
+                                (size_t)nnz, 0, bits, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_ptr_from_sorted, dim3(grid_1d((long long)m + 1, 256)), dim3(256), 0, st, m, nnz,
+                     (const int *)sorted_keys, col_ptr);
+  DGNN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rows_uniform, dim3(grid_1d(nnz, 256)), dim3(256), 0, st, nnz, k, (const int *)permute, row_ind);
+  DGNN_LAUNCH_CHECK();
+  return DGNN_OK;
+}
+size_t transpose_uniform_lists_workspace_bytes(int m, int k) {
+  const long long nnz64 = (long long)m * k;
+  if (m <= 0 || k <= 0 || nnz64 > 0x7fffffffLL) return 0;
+  size_t temp = 0;
+  if (sort_temp_bytes((int)nnz64, key_bits(m), &temp) != hipSuccess) return 0;
+  return 2 * align_up(sizeof(int) * (size_t)nnz64, 256) + align_up(temp, 256);
 }
 
 }  // namespace dgnn

@@ -552,10 +552,6 @@ __global__ __launch_bounds__(256) void k_pack_rows(long long total, int wv, cons
 // grad_src[s,c] = sum over the points r that list s among their neighbours, ascending r, of
 // grad_out[r,c] where max_idx[r,c] == s.  Same values as the scatter of k_edgeconv_bwd, summed in
 // a fixed order and without float atomics (whose 64 lanes land in up to k different rows).
-__global__ void k_fill_list_ptr(int m, int k, int *__restrict__ ptr) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i <= m; i += (long long)gridDim.x * blockDim.x)
-    ptr[i] = (int)(i * k);
-}
 template <int VEC>
 __global__ __launch_bounds__(256) void k_edgeconv_bwd_gather(long long total, int slots, int F,
                                                              const int *__restrict__ col_ptr,
@@ -789,15 +785,14 @@ int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const in
   hipStream_t st = (hipStream_t)stream;
   const int nnz = m * k;
   char *w = (char *)workspace;
-  int *list_ptr = (int *)w;               w += edgeconv_det_align(sizeof(int) * ((size_t)m + 1));
+  w += edgeconv_det_align(sizeof(int) * ((size_t)m + 1));      // (the size function's layout: a row_ptr array no longer made)
   int *col_ptr = (int *)w;                w += edgeconv_det_align(sizeof(int) * ((size_t)m + 1));
   int *row_ind = (int *)w;                w += edgeconv_det_align(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
-  int *perm = (int *)w;                   w += edgeconv_det_align(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
-  const size_t sort_bytes = dgnn_csr2csc_workspace_bytes(m, m, nnz);
-  hipLaunchKernelGGL(k_fill_list_ptr, dim3(grid_1d((long long)m + 1, 256)), dim3(256), 0, st, m, k, list_ptr);
-  DGNN_LAUNCH_CHECK();
-  // the k-NN lists are the CSR of an m x m matrix (row = point, columns = its neighbours)
-  int rc = dgnn_csr2csc(m, m, nnz, list_ptr, src_ind, col_ptr, row_ind, perm, w, sort_bytes, stream);
+  // the k-NN lists are the CSR of an m x m matrix with exactly k entries per row (row = point, columns
+  // = its neighbours): transposed without a row_ptr array or expanded rows (convert.hip); the rest of the
+  // workspace (laid out for dgnn_csr2csc by the size function above) is the sort's
+  const size_t used = (size_t)(w - (char *)workspace);
+  int rc = dgnn::transpose_uniform_lists(m, k, src_ind, col_ptr, row_ind, w, workspace_bytes - used, st);
   if (rc) return rc;
   const bool vec4 = (f % 4 == 0) && ((((uintptr_t)max_idx | (uintptr_t)grad_out | (uintptr_t)grad_src) & 15u) == 0);
   const int slots = vec4 ? f / 4 : f;
