@@ -62,6 +62,8 @@ struct BwdParams {
   int dim;
   int grad_sum;        // BWD_GMM: grad is [m,F], the gradient of the output SUMMED over the kernels
                        // (every kernel's lanes read the same row slice): gmmconv_layer.py:58 folded in
+  int hreg;            // BWD_GMM with grad_sum, F <= 64: an entry takes pack_s = max(4, F/4) lanes and the
+                       // kernels' slices and accumulators sit in registers (see run_hreg)
 };
 
 enum { BWD_GAT = 0, BWD_GMM = 1 };
@@ -73,9 +75,9 @@ static inline int bwd_group_size(int H, int nnz, bool narrow = false) {
   if (!(v == 64 || v == 128 || v == 256)) return shrink_group_for_small_graphs(dflt, nnz, 64);
   return (H > 4 && v > 128) ? 128 : v;
 }
-static inline size_t bwd_lds_bytes(int H, int L) {
-  // per wave: cell float2 [L][H] + kof[L] + colk[L] + dq[L] + stream[2L]
-  return (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)L * H * 2 + (size_t)L * 5) * sizeof(float);
+static inline size_t bwd_lds_bytes(int H, int L, bool hreg = false) {
+  // per wave: cell float2 [L][H] + kof[L] + colk[L] + dq[L] + stream[2L] (hreg: stream[(H + 1) L])
+  return (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)L * H * 2 + (size_t)L * 5 + (hreg ? (size_t)L * (H - 1) : 0)) * sizeof(float);
 }
 
 // Lane -> (head, feature slice) map shared by the backward kernels: in the pass that starts at
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
   if (BMODE == BWD_GAT) drop_resolve(P.rng);
-  constexpr size_t per_wave_floats = (size_t)L * HC * 2 + (size_t)L * 5;
+  // (hreg: the stream holds HC U steps per column instead of one: (HC + 1) L words, bwd_lds_bytes)
+  const size_t per_wave_floats = (size_t)L * HC * 2 + (size_t)L * 5 + ((BMODE == BWD_GMM && P.hreg) ? (size_t)L * (HC - 1) : 0);
   float2 *cell = (float2 *)(lds_raw + (size_t)wib * per_wave_floats);  // [L][HC] {±w, B -> d}
   unsigned *kof = (unsigned *)(cell + (size_t)L * HC);                  // [L] column ordinal | END
   int *colk = (int *)(kof + L);                                         // [L] column id of ordinal k
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       if constexpr (STEADY) {
         if (packed) {
           const int G = DGNN_WAVE / P.pack_s;
-          const int mine = nonempty ? 1 + (b - a + G - 1) / G : 0;
+          const int NU = (BMODE == BWD_GMM && P.hreg) ? H : 1;      // U steps per column
+          const int mine = nonempty ? NU + (b - a + G - 1) / G : 0;
           int incl = mine;                                  // inclusive prefix sum over the lanes
 #pragma unroll
           for (int off = 1; off < DGNN_WAVE; off <<= 1) {
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           }
           if (nonempty) {
             int pos = nsteps + incl - mine;
-            stream[pos++] = (unsigned)c | DGNN_BWD_UFLAG;
+            for (int q = 0; q < NU; ++q) stream[pos++] = (unsigned)c | DGNN_BWD_UFLAG;
             for (int p0 = a; p0 < b; p0 += G)
               stream[pos++] = (unsigned)p0 | ((unsigned)(min(G, b - p0) - 1) << 10) | (p0 + G >= b ? DGNN_PACK_END : 0u);
           }
@@ -399,6 +403,117 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         // (profiles/r2h_pmc_sq_gmmsum16_reddit.csv).  FVC = 0 keeps the run-time widths (shapes
         // whose row width is not max(4, HC * fv)).
         took_steady = true;
+        // ---- BWD_GMM with the summed gradient: every kernel reads the SAME grad slice, so an entry
+        // takes SC = max(4, F/4) lanes (not kernels x F/4), a step 64 / SC entries, and the lane keeps
+        // the column's feature slice and the accumulator of EVERY kernel in registers: one grad load
+        // per entry instead of one per kernel, and (K = 3 x 64) four entries per step instead of one.
+        // The column's own rows arrive as H consecutive U steps (kernel 0, 1, ...).
+        bool ran_hreg = false;
+        if constexpr (BMODE == BWD_GMM) {
+          if (P.hreg) {
+            ran_hreg = true;
+            auto run_hreg = [&](auto scc) {
+              constexpr int SC = decltype(scc)::value;
+              const int g = lane / SC, qq = lane % SC;
+              const bool act = qq * 4 < P.F;
+              const size_t qoff = act ? (size_t)qq * 4 : 0;
+              float4 uh[HC], acch[HC];
+#pragma unroll
+              for (int h = 0; h < HC; ++h) uh[h] = acch[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+              int iu = 0, cu = 0;       // kernel of the next U step: issue side, consume side (wave-uniform)
+              auto issue = [&](int j, float4 &x) {
+                const unsigned it = (unsigned)uniform_i32((int)stream[j]);
+                if (it & DGNN_BWD_UFLAG) {
+                  x = *(const float4 *)(P.in_feat + (size_t)(it & DGNN_BWD_IDMASK) * P.HF + (size_t)iu * P.F + qoff);
+                  iu = (iu + 1 == H) ? 0 : iu + 1;
+                } else {
+                  const int p0 = (int)(it & 1023u), n = (int)((it >> 10) & 15u) + 1;
+                  const unsigned r = kof[p0 + (g < n ? g : 0)];
+                  x = *(const float4 *)(P.grad + (size_t)r * P.F + qoff);
+                }
+              };
+              auto consume = [&](const float4 &x, int j) {
+                const unsigned it = (unsigned)uniform_i32((int)stream[j]);
+                if (it & DGNN_BWD_UFLAG) {
+#pragma unroll
+                  for (int h = 0; h < HC; ++h)
+                    if (cu == h) uh[h] = x;
+                  if (cu == 0) ++k;
+                  cu = (cu + 1 == H) ? 0 : cu + 1;
+                  return;
+                }
+                const int p0 = (int)(it & 1023u), n = (int)((it >> 10) & 15u) + 1;
+                const bool live = g < n;
+                float2 *cp = cell + (size_t)(p0 + (live ? g : 0)) * HC;
+#pragma unroll
+                for (int h = 0; h < HC; ++h) {
+                  if (h >= H) break;
+                  const float w = live ? fabsf(cp[h].x) : 0.f;
+                  float dot = act ? vec_dot<4>(x, uh[h]) : 0.f;
+                  dot += dpp_f32<DGNN_DPP_QUAD_XOR1>(dot);
+                  dot += dpp_f32<DGNN_DPP_QUAD_XOR2>(dot);
+                  if constexpr (SC >= 8) dot += dpp_f32<DGNN_DPP_ROW_HALF_MIRROR>(dot);
+                  if constexpr (SC >= 16) dot += dpp_f32<DGNN_DPP_ROW_MIRROR>(dot);
+                  V::fma(acch[h], w, x);
+                  if (qq == 0 && live) cp[h].y = dot;
+                }
+                if (it & DGNN_PACK_END) {
+                  const int dst = uniform_i32(dq[k]);
+                  float *base = dst >= 0 ? P.grad_feat + (size_t)dst * P.HF
+                                         : P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
+#pragma unroll
+                  for (int h = 0; h < HC; ++h) {
+                    if (h >= H) break;
+#pragma unroll
+                    for (int off = SC; off < DGNN_WAVE; off <<= 1) {
+                      acch[h].x += __shfl_xor(acch[h].x, off, DGNN_WAVE);
+                      acch[h].y += __shfl_xor(acch[h].y, off, DGNN_WAVE);
+                      acch[h].z += __shfl_xor(acch[h].z, off, DGNN_WAVE);
+                      acch[h].w += __shfl_xor(acch[h].w, off, DGNN_WAVE);
+                    }
+                    if (g == 0 && act) *(float4 *)(base + (size_t)h * P.F + qoff) = acch[h];
+                    acch[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                  }
+                }
+              };
+              int j = 0;
+              if (nsteps >= 2 * DGNN_FAST_U) {
+#pragma unroll
+                for (int i = 0; i < DGNN_FAST_U; ++i) {
+                  issue(i, ring[i]);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                for (; j + 2 * DGNN_FAST_U <= nsteps; j += DGNN_FAST_U) {
+#pragma unroll
+                  for (int i = 0; i < DGNN_FAST_U; ++i) {
+                    consume(ring[i], j + i);
+                    issue(j + i + DGNN_FAST_U, ring[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+                }
+#pragma unroll
+                for (int i = 0; i < DGNN_FAST_U; ++i) {
+                  const float4 x = ring[i];
+                  if (j + i + DGNN_FAST_U < nsteps) issue(j + i + DGNN_FAST_U, ring[i]);
+                  consume(x, j + i);
+                }
+                j += DGNN_FAST_U;
+#pragma unroll
+                for (int i = 0; i < DGNN_FAST_U; ++i)
+                  if (j + i < nsteps) consume(ring[i], j + i);
+              } else {
+                for (; j < nsteps; ++j) {
+                  float4 x;
+                  issue(j, x);
+                  consume(x, j);
+                }
+              }
+            };
+            if (P.pack_s == 16) run_hreg(std::integral_constant<int, 16>{});
+            else if (P.pack_s == 8) run_hreg(std::integral_constant<int, 8>{});
+            else run_hreg(std::integral_constant<int, 4>{});
+          }
+        }
         auto run_packed = [&](auto fvc) {
         constexpr int FVC = decltype(fvc)::value;
         constexpr int SC = FVC == 0 ? 0 : (HC * FVC > 4 ? HC * FVC : 4);
@@ -516,7 +631,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         };   // run_packed
         const int want_s = HC * P.fv > 4 ? HC * P.fv : 4;
         const bool spec = P.pack_s == want_s && P.fv_const != 0;
-        bool ran = false;
+        bool ran = ran_hreg;
         if (spec) {
           if constexpr (HC * 16 <= 16) { if (!ran && P.fv == 16) { run_packed(std::integral_constant<int, 16>{}); ran = true; } }
           if constexpr (HC * 8 <= 16)  { if (!ran && P.fv == 8)  { run_packed(std::integral_constant<int, 8>{});  ran = true; } }

@@ -853,10 +853,22 @@ static bool gmm_backward_fused_shape(int nodes, int kernels, int embed) {
   return kernels * bwd_lanes_per_head(embed, embed % 4 == 0 ? 4 : 1) <= DGNN_WAVE;
 }
 
+// The summed-gradient form with the kernels in registers (k_bwd_col_gather, run_hreg): float4 rows of
+// 17 .. 64 features; its groups hold at most 128 entries (the longer stream has to fit in LDS).
+// Measured, K = 3, forward + backward in ms without / with it (profiles/r2i_gmm_hreg_ab.txt): Reddit shape
+// F = 64 24.3 / 20.1, F = 32 19.1 / 13.6, F = 16 11.3 / 11.1; products shape 16.3 / 14.7, 12.5 / 10.4,
+// 8.1 / 8.8 -- at 16 features the K extra U steps of every short column cost more than the packing
+// saves, and the pass is bound by the edge-order gathers of pseudo / scatters of grad_gauss anyway.
+static bool gmm_hreg_shape(int kernels, int embed) {
+  return embed % 4 == 0 && embed > 16 && embed <= 64 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_GMM_HREG", 1) != 0 &&
+         env_int("DGNN_BWD_STEADY", 1) != 0 && env_int("DGNN_BWD_PACK", 1) != 0;
+}
+
 size_t dgnn_gmm_backward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
   if (nodes < 0 || nnz < 0 || kernels <= 0 || embed <= 0) return 0;
   if (!gmm_backward_fused_shape(nodes, kernels, embed)) return 0;
-  const int L = bwd_group_size(bwd_heads_padded(kernels), nnz, narrow_rows(kernels, embed));
+  int L = bwd_group_size(bwd_heads_padded(kernels), nnz, narrow_rows(kernels, embed));
+  if (gmm_hreg_shape(kernels, embed) && L > 128) L = 128;      // either form of the gradient fits
   const size_t T = ((size_t)nnz + L - 1) / L;
   const size_t stride = align_up((size_t)kernels * embed + kernels, 4);
   return align_up(sizeof(int) * (T > 0 ? T : 1), 256) + align_up(sizeof(float) * 2 * T * stride, 256);
@@ -885,10 +897,15 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
   P.n = nodes; P.m = nodes; P.nnz = nnz; P.H = kernels; P.F = embed; P.HF = kernels * embed;
   const int hc = bwd_heads_padded(kernels);
   P.L = bwd_group_size(hc, nnz, narrow_rows(kernels, embed));
-  P.T = (nnz + P.L - 1) / P.L;
   P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
   P.steady = (vec == 4 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
   P.pack_s = bwd_pack_lanes(P.steady != 0, kernels, P.fv);
+  P.hreg = (grad_sum && vec == 4 && P.steady && gmm_hreg_shape(kernels, embed)) ? 1 : 0;
+  if (P.hreg) {
+    P.pack_s = P.fv > 4 ? P.fv : 4;              // lanes per entry: the row's float4 slots, a power of two
+    if (P.L > 128) P.L = 128;
+  }
+  P.T = (nnz + P.L - 1) / P.L;
   P.fv_const = env_int("DGNN_BWD_PACK_CONST", 1);
   P.slot_stride = (int)align_up((size_t)kernels * embed + kernels, 4);
   P.col_ptr = col_ptr; P.row_ind = row_ind; P.permute = permute;
@@ -906,7 +923,7 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
   }
   if (P.T > 0) {
     const dim3 grid(blocks_for_waves(P.T)), block(DGNN_BLOCK);
-    launch_bwd_gather<BWD_GMM>(P, hc, vec, grid, block, bwd_lds_bytes(hc, P.L), st);
+    launch_bwd_gather<BWD_GMM>(P, hc, vec, grid, block, bwd_lds_bytes(hc, P.L, P.hreg != 0), st);
     DGNN_LAUNCH_CHECK();
     if (P.T > 1) {
       if (vec == 4)

@@ -679,13 +679,17 @@ def test_gmm_autograd_operator(nat, f, pad_rows):
 
 
 @pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
-@pytest.mark.parametrize("k,f", [(3, 64), (2, 16), (3, 16), (1, 8), (5, 8), (3, 41), (2, 100), (8, 64)])
+@pytest.mark.parametrize("k,f", [(3, 64), (2, 16), (3, 16), (1, 8), (5, 8), (3, 41), (2, 100), (8, 64),
+                                 (2, 32), (1, 64), (3, 36), (5, 32), (4, 20), (7, 32)])
 @pytest.mark.parametrize("fwd_l", [0, 64])
 def test_gmm_sum_over_kernels_folded_into_the_operator(nat, name, k, f, fwd_l, monkeypatch):
     """GmmConvFuseSum == GmmConvFuse(...).sum(1) (dgNN/layers/gmmconv_layer.py:58) with the sum in
     the kernels' store and the gradient's expand in the one-pass backward: forward and every
     gradient against float64 torch autograd; rows cut by group boundaries (small groups forced on
-    the hub graph) take the partial-slot path; 8 x 64 is outside the summed kernels (fallback)."""
+    the hub graph) take the partial-slot path; 8 x 64 is outside the summed kernels (fallback).
+    Widths of 17 .. 64 features take the backward that keeps the kernels' slices in registers
+    (run_hreg in csrc/gat_bwd_fast.hpp: 1 .. 7 kernels, 8- and 16-lane entries, rows that do not fill
+    their lanes), the others the lane-per-kernel form."""
     from dgnn_amd.operators import GmmConvFuseSum
     if fwd_l:
         monkeypatch.setenv("DGNN_FWD_L", str(fwd_l))

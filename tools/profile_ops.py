@@ -31,7 +31,7 @@ def gmm(workload, summed=False):
         g = random_graph(19717, 88648, 0)
         g = {k: (torch.from_numpy(v).to(dev) if hasattr(v, "shape") else v) for k, v in g.items()}
     else:
-        g = bench.build_graph("reddit", dev)
+        g = bench.build_graph(os.environ.get("DGNN_PROFILE_GMM_GRAPH", "reddit"), dev)    # or "products": short columns
     K, D, F = 3, 2, int(os.environ.get("DGNN_PROFILE_GMM_F", "64"))     # 16: the reference script's default width
     gen = torch.Generator(device=dev); gen.manual_seed(0)
     x = torch.randn((g["n"], K, F), device=dev, generator=gen).requires_grad_()
