@@ -39,6 +39,8 @@ WORKLOADS = {
 H, F = 4, 64
 SLOPE = 0.2
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# collectives of a bench run take milliseconds: a rank that waits this long has lost a peer
+PG_TIMEOUT = __import__("datetime").timedelta(seconds=int(os.environ.get("DGNN_PG_TIMEOUT", "120")))
 
 
 def rmat_edges(n, target, scale, device, seed, abcd=(0.57, 0.19, 0.19, 0.05)):
@@ -179,23 +181,57 @@ def self_launch(n_ranks, argv):
     pass rank 0's stdout through.  No exec: the children are ordinary subprocesses."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # Watchdog: every child is polled; the first rank that exits non-zero (bad device index, OOM,
+    # import error) takes the others down within seconds -- they would otherwise sit in RCCL's
+    # bootstrap or in a collective until the process-group timeout -- and an overall limit
+    # (DGNN_BENCH_LAUNCH_TIMEOUT seconds, default 900) bounds the whole run.
+    limit = float(os.environ.get("DGNN_BENCH_LAUNCH_TIMEOUT", "900"))
     procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
-                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    out0 = tempfile.TemporaryFile()           # rank 0's stdout (the JSON line): a file, so nothing blocks on a pipe
+    try:
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                       LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        t0 = time.monotonic()
+        why = None
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if any(c not in (None, 0) for c in codes):
+                why = "a rank failed"
+                break
+            if time.monotonic() - t0 > limit:
+                why = f"no result after {limit:.0f} s"
+                break
+            time.sleep(0.2)
+    finally:
+        # the exact children started above, by pid: terminate, then kill what ignores it
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in live) and time.monotonic() - t1 < 10.0:
+            time.sleep(0.1)
+        for p in live:
+            if p.poll() is None:
+                p.kill()
+        codes = [p.wait() for p in procs]
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
+    out0.close()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    if why is not None or bad:
+        print(f"bench.py: {why or 'ranks failed'}; (rank, exit code) of the ranks that did not exit 0: {bad}",
+              file=sys.stderr)
         return 1
     return 0
 
@@ -207,8 +243,10 @@ def dry_run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     seen, backend = 1, None
+    if os.environ.get("DGNN_BENCH_DRY_FAIL_RANK") == str(rank) and "RANK" in os.environ:
+        sys.exit(3)        # launcher test: a rank that dies before the rendezvous (tests/test_bench_launcher.py)
     if "RANK" in os.environ:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=PG_TIMEOUT)
         t = torch.ones(1)
         dist.all_reduce(t)
         seen, backend = int(t.item()), dist.get_backend()
@@ -267,7 +305,7 @@ def main():
         json_fd = os.dup(1)
         os.dup2(2, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=PG_TIMEOUT)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 

@@ -284,6 +284,7 @@ class PartitionedGAT:
         self.last_bwd = (self.b_blocks[-1][1] - self.b_blocks[-1][0], self.b_blocks[-1][3].numel())
         self._ctx = None
         self._tables = {}
+        self._pair_agreed = {}      # (heads, features) -> every rank's forward produced the negative-score pair
 
     # ------------------------------------------------------------------ collectives
     def _nccl(self):
@@ -315,6 +316,19 @@ class PartitionedGAT:
         dist.all_to_all_single(o, inp.contiguous().cpu(), out_splits, in_splits, group=self.group)
         out.copy_(o)
         return None
+
+    def _agree_on_pair(self, key, mine):
+        """The backward issues different collectives with and without the forward's negative-score
+        pair (no return exchange with it), so one rank falling back alone would pair an all-to-all
+        with nothing and hang the group: the pair is used only if EVERY rank has it (one MIN
+        all-reduce at the first forward of a shape, remembered afterwards)."""
+        if not self._solo:
+            dev = self.device if self._nccl() else torch.device("cpu")
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            mine = bool(int(flag.item()))
+        self._pair_agreed[key] = mine
+        return mine
 
     @staticmethod
     def _wait(handles):
@@ -476,23 +490,48 @@ class PartitionedGAT:
             out = torch.empty((self.n_loc,) + tuple(in_feat_loc.shape[1:]), dtype=in_feat_loc.dtype, device=in_feat_loc.device)
             emax = torch.empty((self.n_loc, h), dtype=in_feat_loc.dtype, device=in_feat_loc.device)
             esum = torch.empty_like(emax)
-            # the negative-score pair: grad_attn_row then needs nothing from other ranks (backward)
-            want_neg = getattr(self.ops, "supports_neg", False) and in_feat_loc.size(-1) % 4 == 0
+            # the negative-score pair: grad_attn_row then needs nothing from other ranks (backward).
+            # Whether the pair is used decides WHICH collectives the backward issues (with it no
+            # partial rows travel back), so it must be the same on every rank: the first forward of
+            # a shape agrees on it over the group (_agree_on_pair) and later steps reuse the answer.
+            key = (h, in_feat_loc.size(-1))
+            agreed = self._pair_agreed.get(key)
+            want_neg = getattr(self.ops, "supports_neg", False) and in_feat_loc.size(-1) % 4 == 0 and agreed is not False
             out_neg = torch.empty_like(out) if want_neg else None
             a_neg = torch.empty_like(emax) if want_neg else None
             streams = self._chunk_streams(in_feat_loc.device)
             for s, (a, b, ptr, ind, n_vis) in enumerate(side.blocks):   # every chunk writes its own rows
                 with (torch.cuda.stream(streams[s % 2]) if streams is not None else contextlib.nullcontext()):
                     self._wait(handles[s])
+                    if b == a:                         # an empty chunk writes nothing (and decides nothing)
+                        continue
+                    # the kernels move the [rows,h] tensors as 16-byte vectors: a chunk whose first row
+                    # is not 16-byte aligned inside them (h = 1, 2, 3, 5 ... and an odd cut) gets
+                    # aligned temporaries, copied into place (a few KB) -- the kernel choice, and with
+                    # it the pair, must not depend on where a rank's cuts happen to fall
+                    direct = (a * h) % 4 == 0
+                    small = (emax[a:b], esum[a:b], a_neg[a:b] if want_neg else None) if direct else \
+                        tuple(torch.empty((b - a, h), dtype=emax.dtype, device=emax.device) if t is not None else None
+                              for t in (emax, esum, a_neg if want_neg else None))
                     if want_neg:
                         res = self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
-                                                   out=(out[a:b], emax[a:b], esum[a:b], out_neg[a:b], a_neg[a:b]), neg=True)
+                                                   out=(out[a:b], small[0], small[1], out_neg[a:b], small[2]), neg=True)
                         if res[3] is None:             # shape outside the pair's kernels: the edge-gradient path
+                            if agreed:
+                                raise RuntimeError("dgnn_amd.dist: the ranks agreed on the negative-score pair for this "
+                                                   "shape, but a chunk's forward did not produce it")
                             want_neg, out_neg, a_neg = False, None, None
                     else:
                         self.ops.gat_forward(attn_row_loc[a:b], ac_tab[:n_vis], ptr, ind, slope, in_tab[:n_vis],
-                                             out=(out[a:b], emax[a:b], esum[a:b]))
+                                             out=(out[a:b], small[0], small[1]))
+                    if not direct:
+                        emax[a:b].copy_(small[0])
+                        esum[a:b].copy_(small[1])
+                        if want_neg:
+                            a_neg[a:b].copy_(small[2])
             self._join_streams(streams, in_feat_loc.device)
+            if agreed is None:
+                want_neg = self._agree_on_pair(key, want_neg)
             self._neg = (out_neg, a_neg) if want_neg else None
         else:
             in_tab, ac_tab = self._all_gather_rows(in_feat_loc), self._all_gather_rows(attn_col_loc)
@@ -559,6 +598,9 @@ class PartitionedGAT:
             # every chunk writes its own columns of grad_feat / grad_attn_col; its grad_attn_row
             # is a partial sum over the table rows it can see
             outs = (gf[a:b], None, gc[a:b])
+            if b == a:                      # an empty chunk: no columns to write, no partial rows
+                self._wait(handles[s])
+                continue
             if local_gr is not None:
                 with (torch.cuda.stream(streams[s % 2]) if streams is not None else contextlib.nullcontext()):
                     self._wait(handles[s])
@@ -567,10 +609,10 @@ class PartitionedGAT:
                                                        need_grad_attn_row=False)
                 if res is not None:
                     continue
-                self._join_streams(streams, gf.device)
-                streams = None
-                local_gr = None             # (cannot happen for shapes the pair exists for; keep the old path whole)
-                gr_tab = torch.zeros((stat_tab.size(0), stat_tab.size(1)), dtype=stat_tab.dtype, device=stat_tab.device)
+                # falling back HERE would issue a return exchange the other ranks do not: fail loudly
+                # (cannot happen for shapes the pair exists for: float4 rows, 16-byte records)
+                raise RuntimeError("dgnn_amd.dist: the packed column pass refused a shape the forward produced the "
+                                   "negative-score pair for")
             else:
                 self._wait(handles[s])
             res = self.ops.gat_backward_packed(slope, rptr, cind, cptr, rind, perm, stat_tab[:n_vis],

@@ -6,7 +6,10 @@ mode "cpu": gloo backend, CPU tensors, compute through a CPU stand-in built on t
 mode "cpuneg": the same with a stand-in that also produces the forward's negative-score pair, so the
             runner takes the path on which a row's owner computes grad_attn_row alone (no return
             exchange; dgnn_amd/dist.py).
+mode "cpunegmix": the pair is missing on rank 1 only: every rank must fall back together.
 mode "gpu": gloo backend, every rank on cuda:0, compute through the real HIP kernels.
+mode "nccl": rank r on cuda:r with the nccl (= RCCL) backend: the multi-GPU path as it runs in
+            production; needs a GPU per rank (tests skip themselves on a one-GPU box).
 mode "nccl1": ONE rank on cuda:0 with the nccl (= RCCL) backend and DGNN_DIST_FORCE_COLLECTIVES=1:
             every collective of the step is really issued through RCCL (RCCL wants one GPU per
             rank, so one rank is what a one-GPU box can rehearse).
@@ -130,21 +133,44 @@ class OracleOpsNeg(OracleOps):
         return self._emit((gf, None, gc), out)
 
 
+class OracleOpsNegOnSomeRanks(OracleOpsNeg):
+    """The pair exists on every rank but `missing_on`: what misaligned chunk cuts or an empty chunk
+    used to cause on the GPU.  The runner has to notice and take the returning path on
+    EVERY rank; ranks that disagree pair an all-to-all with nothing and hang."""
+
+    def __init__(self, rank, missing_on=1):
+        super().__init__()
+        self.missing = rank == missing_on
+
+    def gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=None, neg=False):
+        if neg and self.missing:
+            base = OracleOps.gat_forward(self, attn_row, attn_col, row_ptr, col_ind, slope, in_feat)
+            return self._emit(base, None if out is None else out[:3]) + (None, None)
+        return super().gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, out=out, neg=neg)
+
+
 def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if mode == "nccl1":      # one rank, RCCL backend, collectives forced: rehearses the calls on one GPU
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    elif mode == "nccl":
+        from datetime import timedelta
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"),
+                                timeout=timedelta(seconds=120))
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from datetime import timedelta
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
     from util import gat_inputs, rmat_graph
     from dgnn_amd.dist import PartitionedGAT
     g = rmat_graph(*graph_spec)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
-    device = torch.device("cpu" if mode in ("cpu", "cpuneg") else "cuda:0")
+    device = torch.device("cpu" if mode in ("cpu", "cpuneg", "cpunegmix") else f"cuda:{rank}" if mode == "nccl" else "cuda:0")
     G = {k: torch.from_numpy(g[k]).to(device) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
-    ops = OracleOps() if mode == "cpu" else OracleOpsNeg() if mode == "cpuneg" else None
+    ops = (OracleOps() if mode == "cpu" else OracleOpsNeg() if mode == "cpuneg" else
+           OracleOpsNegOnSomeRanks(rank) if mode == "cpunegmix" else None)
     runner = PartitionedGAT(G, world, rank, device, ops=ops)
     lo, hi = runner.lo, runner.hi
     t = lambda a: torch.from_numpy(a).to(device)
@@ -156,6 +182,15 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     gf, gr, gc = runner.backward(t(grad[lo:hi]))
     if mode == "cpuneg" and runner.mode == "halo":
         assert runner._neg is not None, "the stand-in offers the pair: the runner must take the owner-local path"
+    if mode == "cpunegmix" and runner.mode == "halo" and world > 1:
+        assert runner._neg is None, "one rank lacks the pair: NO rank may take the owner-local path"
+    if mode in ("gpu", "nccl") and runner.mode == "halo" and f % 4 == 0 and h <= 8:
+        assert runner._neg is not None, "float4 rows: the HIP forward must produce the pair on every rank"
+    if mode in ("cpuneg", "cpunegmix", "gpu", "nccl"):      # a second step takes the remembered decision
+        out2 = runner.forward(x_loc, t(attn_row[lo:hi]), t(attn_col[lo:hi]), 0.2)
+        gf2, gr2, gc2 = runner.backward(t(grad[lo:hi]))
+        for u, v in ((out, out2), (gf, gf2), (gr, gr2), (gc, gc2)):
+            assert torch.equal(u, v), "the second step must repeat the first bit for bit"
     if device.type == "cuda":
         torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo, hi=hi, out=out.cpu().numpy(),

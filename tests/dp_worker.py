@@ -5,6 +5,7 @@ mode "cpu": gloo, CPU tensors, float64; the model is a pure-torch statement of t
             stack (k-NN graph, EdgeConv as gather + max, pooling, linear head): the test is
             about the split, the parameter broadcast and the weighted gradient all-reduce.
 mode "gpu": gloo, every rank on cuda:0, dgnn_amd.layers.EdgeConv / KNNGraph (the HIP kernels).
+mode "nccl": the real thing where the box has a GPU per rank: rank r on cuda:r, RCCL collectives.
 Rank r seeds its parameters with 100 + r, so the broadcast from rank 0 is really needed.
 Each rank writes its reduced gradients and its parameters to <out_dir>/rank<r>.npz.
 """
@@ -21,6 +22,9 @@ ROOT = os.path.dirname(HERE)
 for p in (ROOT, HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+GPU = "cuda:0"           # the device of the GPU modes ("nccl": cuda:<rank>, set in run())
 
 
 def knn_torch(x, k):
@@ -71,7 +75,7 @@ def build(mode, k, seed):
     if mode == "cpu":
         return SmallDGCNN(k, TorchEdgeConv, lambda h: knn_torch(h, k)).double()
     from dgnn_amd.layers import EdgeConv, KNNGraph
-    return SmallDGCNN(k, EdgeConv, KNNGraph(k)).to("cuda:0")
+    return SmallDGCNN(k, EdgeConv, KNNGraph(k)).to(GPU)
 
 
 def data(mode, batch, points):
@@ -80,7 +84,7 @@ def data(mode, batch, points):
     y = torch.randint(0, 5, (batch,), generator=g)
     if mode == "cpu":
         return x, y
-    return x.float().to("cuda:0"), y.to("cuda:0")
+    return x.float().to(GPU), y.to(GPU)
 
 
 def grads_of(model):
@@ -91,7 +95,15 @@ def grads_of(model):
 def run(rank, world, mode, port, out_dir, batch, points, k):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datetime import timedelta
+    if mode == "nccl":
+        global GPU
+        GPU = f"cuda:{rank}"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(GPU),
+                                timeout=timedelta(seconds=120))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
     from dgnn_amd.dist import CloudDataParallel
     model = build(mode, k, seed=100 + rank)
     dp = CloudDataParallel(model, batch, world, rank)

@@ -43,3 +43,27 @@ def test_under_torchrun_the_flag_must_agree_with_the_world_size():
     bad = subprocess.run(base + ["--master-port", "29542", BENCH, "--gpus", "4", "--dry"], capture_output=True,
                          text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_a_dead_rank_takes_the_launch_down_within_seconds():
+    """VERDICT r2 / ADVICE: the parent used to block on rank 0 while rank 0 waited for a peer that had
+    died.  Rank 1 exits before the rendezvous; rank 0 would wait for it until the process-group
+    timeout: the watchdog must end the run non-zero long before that."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["DGNN_BENCH_DRY_FAIL_RANK"] = "1"
+    env["DGNN_PG_TIMEOUT"] = "600"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0
+    assert "(1, 3)" in r.stderr, r.stderr
+    assert time.monotonic() - t0 < 120
+
+
+def test_the_launch_has_an_overall_time_limit():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["DGNN_BENCH_LAUNCH_TIMEOUT"] = "0.01"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "no result after" in r.stderr

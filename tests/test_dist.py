@@ -95,6 +95,17 @@ def test_partitioned_gat_cpu_gloo_owner_local_grad_attn_row(world, chunks):
     check(run_world(world, "cpuneg", spec, h, f, "halo", chunks), spec, h, f)
 
 
+@pytest.mark.parametrize("world,h", [(2, 2), (3, 1), (4, 3)])
+def test_partitioned_gat_cpu_gloo_ranks_agree_on_the_pair(world, h):
+    """a rank whose forward lacks the negative-score pair used to fall back alone and
+    issue a return exchange nobody else did.  With the pair missing on rank 1 only, every rank
+    must take the returning path (no hang, same results); odd head counts put the chunk cuts at
+    unaligned offsets of the [rows,h] tensors."""
+    spec, f = (10, 700, 6000, 5), 8
+    check(run_world(world, "cpunegmix", spec, h, f, "halo", 4), spec, h, f)
+    check(run_world(world, "cpuneg", spec, h, f, "halo", 4), spec, h, f)
+
+
 def test_chunk_fractions_and_incremental_tables():
     import torch
     from dgnn_amd.dist import PartitionedGAT, chunk_fractions
@@ -116,6 +127,29 @@ def test_chunk_fractions_and_incremental_tables():
 def test_partitioned_gat_gpu_two_ranks(exchange):
     spec, h, f = (12, 4000, 60000, 7), 4, 64
     check(run_world(2, "gpu", spec, h, f, exchange), spec, h, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,f", [(1, 64), (2, 16), (3, 8), (8, 8)])
+def test_partitioned_gat_gpu_two_ranks_unaligned_chunk_cuts(h, f):
+    """Heads 1 / 2 / 3 with four chunks: a chunk's first row sits at a*h*4 bytes of the [rows,h] tensors,
+    16-byte aligned or not depending on where the rank's cuts fall.  Both ranks must
+    produce the pair (asserted in the worker), agree on it and finish."""
+    spec = (12, 4001, 60000, 7)
+    check(run_world(2, "gpu", spec, h, f, "halo", 4), spec, h, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange,h,f", [("halo", 4, 64), ("allgather", 4, 64), ("halo", 1, 16), ("halo", 2, 32)])
+def test_partitioned_gat_nccl_ranks(exchange, h, f):
+    """Real RCCL, one GPU per rank: halo exchange and all-gather against the single-graph oracle.
+    Runs wherever at least two GPUs are visible (the driver's multi-GPU node), skipped on a one-GPU box."""
+    import torch
+    n_gpu = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if n_gpu < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one GPU per rank)")
+    spec = (12, 4001, 60000, 7)
+    check(run_world(min(n_gpu, 4), "nccl", spec, h, f, exchange, 4), spec, h, f)
 
 
 @pytest.mark.gpu

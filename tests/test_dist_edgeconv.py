@@ -70,6 +70,16 @@ def test_cloud_data_parallel_gpu_two_ranks():
     check(run_world(2, "gpu"), "gpu", rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.gpu
+def test_cloud_data_parallel_nccl_ranks():
+    """Real RCCL, one GPU per rank: runs wherever at least two GPUs are visible (the driver's multi-GPU
+    node), skipped on a one-GPU box."""
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one GPU per rank)")
+    check(run_world(min(n_gpu, 4), "nccl"), "gpu", rtol=1e-4, atol=1e-6)
+
+
 def test_cloud_range_covers_the_batch():
     from dgnn_amd.dist import cloud_range
     for batch in (1, 5, 32, 33):
