@@ -456,6 +456,9 @@ int dgnn_gat_forward_tiles(int m, int nnz, int h, int f, float negative_slope,
   if (rc) return rc;
   if (tile_nnz <= 0) return DGNN_ERR_BAD_ARG;
   if (n_tiles < 0 || (n_tiles > 0 && !tile_scheduler) || (m > 0 && !row_ptr)) return DGNN_ERR_BAD_ARG;
+  // no rows: nothing to check against (row_ptr may be NULL) and nothing to compute; a list that
+  // names tiles of a graph without rows is malformed
+  if (m == 0) return n_tiles > 0 ? DGNN_ERR_BAD_ARG : DGNN_OK;
   const size_t fwd_bytes = align_up(fwd_layout(nnz, h, f, true).total, 256);
   if (!workspace || workspace_bytes < fwd_bytes + 256) return DGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;

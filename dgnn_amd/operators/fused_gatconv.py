@@ -17,11 +17,13 @@ _CAPTURE_RNG = {}
 def init_capture_rng(device, seed=None):
     """Create (or reseed) the device {seed, counter} pair dropout draws from under HIP-graph
     capture.  Called implicitly by any eager call with attn_drop > 0."""
-    device = torch.device(device)
     if seed is None:
         seed = int(torch.randint(0, 1 << 62, (1,)).item())
-    _CAPTURE_RNG[device] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
-    return _CAPTURE_RNG[device]
+    state = torch.tensor([seed, 0], dtype=torch.int64, device=torch.device(device))
+    # keyed by the tensor's own device: "cuda" and "cuda:0" are one GPU, and the lookup
+    # (in_feat.device) always carries the index
+    _CAPTURE_RNG[state.device] = state
+    return state
 
 
 def _forward_with_dropout(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):

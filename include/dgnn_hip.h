@@ -92,7 +92,10 @@ int dgnn_gat_forward(int m, int nnz, int h, int f, float attn_drop, float negati
  * arguments, kernels and bits as dgnn_gat_forward.  Limit: dgnn_gat_forward_workspace_bytes(m,
  * nnz, h, f) <= DGNN_NOALLOC_SCRATCH_BYTES (about 15 M edges at 4 x 64), else DGNN_ERR_TOO_LARGE and
  * nothing is launched.  All calls on one GPU share that GPU's array: calls that overlap on one
- * GPU (two streams, two threads) race; serialise them.  Calls no hipMalloc / hipFree. */
+ * GPU (two streams, two threads) race; serialise them.  Calls no hipMalloc / hipFree.
+ * The FIRST call on a device looks the array's address up (hipGetSymbolAddress, which may load the
+ * code object lazily): make that one call eagerly, outside any HIP-graph capture (any size, e.g.
+ * the usual warm-up step); every later call on that device only launches kernels and captures. */
 #define DGNN_NOALLOC_SCRATCH_BYTES (64u << 20)
 int dgnn_gat_forward_noalloc(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
                              const float *attn_row, const float *attn_col, const int *row_ptr,
