@@ -50,10 +50,9 @@ def test_hip_graph_flag_refuses_dropout_before_touching_the_gpu(tmp_path):
     assert p.returncode == 2 and "--dropout 0" in p.stderr
 
 
-@pytest.mark.skipif(os.environ.get("DGNN_TEST_HIP_GRAPH") != "1",
-                    reason="graph capture of a whole training step: run on request (DGNN_TEST_HIP_GRAPH=1)")
 def test_gat_and_monet_examples_replayed_from_a_hip_graph(tmp_path):
-    """--hip-graph: the training epoch captured once and replayed; it still trains."""
+    """--hip-graph: the training epoch captured once and replayed; it still trains.  Every run is a
+    child process (`run`), so a capture gone wrong cannot take the test session's GPU context with it."""
     cols, first, last = run("train_gatconv.py", "--dataset", "cora", "--n-heads", "4", "--n-hidden", "64",
                             "--n-epochs", "30", "--lr", "0.01", "--dropout", "0", "--hip-graph", tmp_path=tmp_path)
     assert cols[1] == "cora heads=4 hidden_dim=64 hip-graph" and last < first
@@ -61,3 +60,19 @@ def test_gat_and_monet_examples_replayed_from_a_hip_graph(tmp_path):
     cols, first, last = run("train_gmmconv.py", "--dataset", "cora", "--n-hidden", "64", "--n-epochs", "30",
                             "--dropout", "0", "--hip-graph", tmp_path=tmp_path)
     assert cols[1].endswith("hip-graph") and last < first
+    # attention dropout under capture: the operator's own generator (device {seed, counter} pair,
+    # dgnn_gat_*_seeded_dev), a fresh mask per replay
+    (tmp_path / "result.csv").unlink()
+    cols, first, last = run("train_gatconv.py", "--dataset", "cora", "--n-heads", "4", "--n-hidden", "64",
+                            "--n-epochs", "30", "--lr", "0.01", "--dropout", "0", "--attn-drop", "0.3", "--hip-graph",
+                            tmp_path=tmp_path)
+    assert cols[1] == "cora heads=4 hidden_dim=64 hip-graph" and last < first
+
+
+def test_operator_dropout_captured_into_a_hip_graph_draws_a_fresh_mask_per_replay():
+    """GATConvFuse with attn_drop = 0.5 captured after an eager warm-up and replayed three times, in a
+    child process of its own (tools/capture_probe.py, case operator_host_seed)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "capture_probe.py"), "operator_host_seed"],
+                       capture_output=True, text=True, timeout=200)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "exit 0" in p.stdout and "every replay drew new random numbers: True" in p.stdout
