@@ -22,6 +22,36 @@ namespace dgnn {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (DGNN_WAVE - 1); }
 __device__ __forceinline__ int wave_in_block() { return threadIdx.x >> 6; }
 
+// 16-byte global accesses at 4-BYTE-aligned addresses.  Feature rows of H*F floats are 16-byte
+// aligned only when H*F is a multiple of four; gfx950 serves global_load/store_dwordx4 at any
+// dword-aligned address at the rate of aligned ones (tools/probe_unaligned.hip: random 656-byte
+// rows 4.90 TB/s unaligned against 4.74 TB/s for the same rows padded to 704 bytes, scalar lanes
+// 1.93 TB/s), so every width of at least four floats takes the float4 lanes: a head's last slot, when
+// F is not a multiple of four, is the four floats that END at the head's end and overlaps its
+// predecessor (both lanes then hold identical values for the shared floats).  The type only
+// drops the compiler's alignment assumption; the instruction is the same dwordx4.
+typedef float dgnn_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ld4u(const float *p) {
+  const dgnn_f4u v = *(const dgnn_f4u *)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4u(float *p, const float4 &v) {
+  dgnn_f4u t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(dgnn_f4u *)p = t;
+}
+// float offset of vector slot q (of ceil(F/4)) inside a head of F >= 4 floats, and the number of
+// its leading components that repeat the previous slot (0 except for the last slot of an F that
+// is not a multiple of four): dot products skip those, sums and stores may keep them
+__device__ __forceinline__ int slot4_off(int q, int F) { return min(q * 4, F - 4); }
+__device__ __forceinline__ int slot4_dup(int q, int F) { return max(q * 4 - (F - 4), 0); }
+__device__ __forceinline__ float4 slot4_mask(float4 v, int dup) {
+  if (dup > 0) v.x = 0.f;
+  if (dup > 1) v.y = 0.f;
+  if (dup > 2) v.z = 0.f;
+  return v;
+}
+
 // fused_gatconv_kernel.cu:13  LeakyRelu(x, s) = x > 0 ? x : x*s
 __device__ __forceinline__ float leaky_relu(float x, float s) { return (x > 0.f) ? x : x * s; }
 

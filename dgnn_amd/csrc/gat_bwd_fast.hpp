@@ -89,6 +89,8 @@ static inline size_t bwd_lds_bytes(int H, int L, bool hreg = false) {
 struct BwdLane {
   bool active, leader;
   int head;
+  int dup;             // float4 lanes, F % 4 != 0: leading components of the head's last slot that repeat
+                       // its predecessor (common.hpp slot4_dup): dot products skip them
   size_t off;          // float offset of the lane's slice inside a feature row
 };
 template <int VEC>
@@ -97,10 +99,19 @@ __device__ __forceinline__ BwdLane bwd_lane(const BwdParams &P, int lane, int hb
   const int head = hb + lane / P.fv, q = lane % P.fv;
   m.active = head < P.H && q * VEC < P.F;
   m.head = m.active ? head : 0;
-  m.off = m.active ? (size_t)head * P.F + (size_t)q * VEC : 0;
+  const int qo = (VEC == 4) ? slot4_off(q, P.F) : q;
+  m.off = m.active ? (size_t)head * P.F + (size_t)qo : 0;
+  m.dup = (VEC == 4 && m.active) ? slot4_dup(q, P.F) : 0;
   m.leader = m.active && q == 0;
   return m;
 }
+// the operand of a dot product: the repeated components of a head's last slot count once
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type dot_operand(const typename VecT<VEC>::type &v, int dup);
+template <>
+__device__ __forceinline__ float4 dot_operand<4>(const float4 &v, int dup) { return slot4_mask(v, dup); }
+template <>
+__device__ __forceinline__ float dot_operand<1>(const float &v, int) { return v; }
 template <int VEC>
 __device__ __forceinline__ float vec_dot(const typename VecT<VEC>::type &a, const typename VecT<VEC>::type &b);
 template <>
@@ -127,10 +138,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
     const BwdLane ln = bwd_lane<VEC>(P, lane_id(), hb);
     float s = 0.f, gn = 0.f;
     vec_t g = VecT<VEC>::zero();
-    if (ln.active && (P.S_in == nullptr || P.out_neg != nullptr)) g = *(const vec_t *)(P.grad + (size_t)r * P.HF + ln.off);
+    if (ln.active && (P.S_in == nullptr || P.out_neg != nullptr))
+      g = dot_operand<VEC>(VecT<VEC>::load(P.grad + (size_t)r * P.HF + ln.off), ln.dup);
     if (P.S_in == nullptr) {
       if (ln.active) {
-        const vec_t o = *(const vec_t *)(P.out_feat + (size_t)r * P.HF + ln.off);
+        const vec_t o = VecT<VEC>::load(P.out_feat + (size_t)r * P.HF + ln.off);
         s = vec_dot<VEC>(g, o);
       }
       s = group_reduce(s, P.fv, OpSum());
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat(BwdParams P) {
     }
     if (P.out_neg != nullptr) {
       if (ln.active) {
-        const vec_t o = *(const vec_t *)(P.out_neg + (size_t)r * P.HF + ln.off);
+        const vec_t o = VecT<VEC>::load(P.out_neg + (size_t)r * P.HF + ln.off);
         gn = vec_dot<VEC>(g, o);
       }
       gn = group_reduce(gn, P.fv, OpSum());
@@ -174,9 +186,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_rowstat_packed(BwdParams P, 
     g[k] = o[k] = on[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok[k]) {
       const size_t at = (size_t)r * P.HF + ln.off;
-      if (need_g) g[k] = *(const float4 *)(P.grad + at);
-      if (P.S_in == nullptr) o[k] = *(const float4 *)(P.out_feat + at);
-      if (P.out_neg != nullptr) on[k] = *(const float4 *)(P.out_neg + at);
+      if (need_g) g[k] = slot4_mask(ld4u(P.grad + at), ln.dup);
+      if (P.S_in == nullptr) o[k] = ld4u(P.out_feat + at);
+      if (P.out_neg != nullptr) on[k] = ld4u(P.out_neg + at);
     }
   }
 #pragma unroll
@@ -424,12 +436,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
               auto issue = [&](int j, float4 &x) {
                 const unsigned it = (unsigned)uniform_i32((int)stream[j]);
                 if (it & DGNN_BWD_UFLAG) {
-                  x = *(const float4 *)(P.in_feat + (size_t)(it & DGNN_BWD_IDMASK) * P.HF + (size_t)iu * P.F + qoff);
+                  x = ld4u(P.in_feat + (size_t)(it & DGNN_BWD_IDMASK) * P.HF + (size_t)iu * P.F + qoff);
                   iu = (iu + 1 == H) ? 0 : iu + 1;
                 } else {
                   const int p0 = (int)(it & 1023u), n = (int)((it >> 10) & 15u) + 1;
                   const unsigned r = kof[p0 + (g < n ? g : 0)];
-                  x = *(const float4 *)(P.grad + (size_t)r * P.F + qoff);
+                  x = ld4u(P.grad + (size_t)r * P.F + qoff);
                 }
               };
               auto consume = [&](const float4 &x, int j) {
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
                       acch[h].z += __shfl_xor(acch[h].z, off, DGNN_WAVE);
                       acch[h].w += __shfl_xor(acch[h].w, off, DGNN_WAVE);
                     }
-                    if (g == 0 && act) *(float4 *)(base + (size_t)h * P.F + qoff) = acch[h];
+                    if (g == 0 && act) st4u(base + (size_t)h * P.F + qoff, acch[h]);
                     acch[h] = make_float4(0.f, 0.f, 0.f, 0.f);
                   }
                 }
@@ -523,22 +535,23 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         const int hd = sl / fv, qq = sl % fv;
         const bool act = hd < H && qq * 4 < P.F;
         const int phead = act ? hd : 0;
-        const size_t poff = act ? (size_t)phead * P.F + (size_t)qq * 4 : 0;
+        const int pq = act ? slot4_off(qq, P.F) : 0;           // the head's last slot may overlap its predecessor
+        const int pdup = act ? slot4_dup(qq, P.F) : 0;
+        const size_t poff = act ? (size_t)phead * P.F + (size_t)pq : 0;
         const bool pleader = act && qq == 0;
-        const size_t pgoff = (BMODE == BWD_GMM && P.grad_sum) ? (size_t)(act ? qq : 0) * 4 : poff;
+        const size_t pgoff = (BMODE == BWD_GMM && P.grad_sum) ? (size_t)pq : poff;
         auto issue = [&](int j, float4 &x) {
           const unsigned it = (unsigned)uniform_i32((int)stream[j]);
           const bool isu = (it & DGNN_BWD_UFLAG) != 0u;
           const int p0 = isu ? 0 : (int)(it & 1023u), n = isu ? 0 : (int)((it >> 10) & 15u) + 1;
           const int pe = p0 + (g < n ? g : 0);
           const unsigned r = isu ? (it & DGNN_BWD_IDMASK) : kof[pe];
-          x = isu ? *(const float4 *)(P.in_feat + (size_t)r * P.HF + poff)
-                  : *(const float4 *)(P.grad + (size_t)r * gstride + pgoff);
+          x = ld4u(isu ? P.in_feat + (size_t)r * P.HF + poff : P.grad + (size_t)r * gstride + pgoff);
         };
         auto consume = [&](const float4 &x, int j) {
           const unsigned it = (unsigned)uniform_i32((int)stream[j]);
           if (it & DGNN_BWD_UFLAG) {
-            u = x;
+            u = slot4_mask(x, pdup);
             ++k;
             return;
           }
@@ -584,11 +597,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
             const int dst = uniform_i32(dq[k]);
             if (g == 0) {
               if (dst >= 0) {
-                if (act) *(float4 *)(P.grad_feat + (size_t)dst * P.HF + poff) = acc;
+                if (act) st4u(P.grad_feat + (size_t)dst * P.HF + poff, acc);
                 if (BMODE == BWD_GAT && pleader) P.grad_attn_col[(size_t)dst * H + phead] = dsum;
               } else {
                 float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
-                if (act) *(float4 *)(sp + poff) = acc;
+                if (act) st4u(sp + poff, acc);
                 if (BMODE == BWD_GAT && pleader) sp[P.HF + phead] = dsum;
               }
             }
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         // one item of the stream, its row already in x
         auto consume = [&](const vec_t &x, unsigned v, int it) {
           if (v & DGNN_BWD_UFLAG) {
-            u = x;
+            u = dot_operand<VEC>(x, ln.dup);
             ++k;
           } else {
             const int p = it - (k + 1);
@@ -664,11 +677,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
             if (v & DGNN_BWD_END) {
               const int dst = uniform_i32(dq[k]);
               if (dst >= 0) {
-                if (active) *(vec_t *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
+                if (active) V::store(P.grad_feat + (size_t)dst * P.HF + lane_off, acc);
                 if (BMODE == BWD_GAT && head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
               } else {
                 float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
-                if (active) *(vec_t *)(sp + lane_off) = acc;
+                if (active) V::store(sp + lane_off, acc);
                 if (BMODE == BWD_GAT && head_leader) sp[P.HF + head] = dsum;
               }
               acc = V::zero();
@@ -684,7 +697,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         // row), a slot consumed before it is refilled
 #pragma unroll
         for (int i = 0; i < DGNN_FAST_U; ++i) {
-          ring[i] = *(const vec_t *)row_of((unsigned)uniform_i32((int)stream[i]));
+          ring[i] = V::load(row_of((unsigned)uniform_i32((int)stream[i])));
           __builtin_amdgcn_sched_barrier(0);
         }
         int j = 0;
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
             const unsigned v = (unsigned)uniform_i32((int)stream[it]);
             const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
             consume(ring[i], v, it);
-            ring[i] = *(const vec_t *)row_of(nv);
+            ring[i] = V::load(row_of(nv));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
               const vec_t x = ring[i];
               const unsigned v = (unsigned)uniform_i32((int)stream[it]);
               if (it + DGNN_FAST_U < items)
-                ring[i] = *(const vec_t *)row_of((unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]));
+                ring[i] = V::load(row_of((unsigned)uniform_i32((int)stream[it + DGNN_FAST_U])));
               consume(x, v, it);
             }
           }
@@ -721,8 +734,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       if (i < items) {
         const unsigned v = (unsigned)uniform_i32((int)stream[i]);
         const bool isu = (v & DGNN_BWD_UFLAG) != 0u;
-        if (active) ring[i] = *(const vec_t *)((isu ? P.in_feat : P.grad) + (size_t)(v & DGNN_BWD_IDMASK) * (isu ? (size_t)P.HF : gstride) +
-                                               (isu ? lane_off : goff));
+        if (active) ring[i] = V::load((isu ? P.in_feat : P.grad) + (size_t)(v & DGNN_BWD_IDMASK) * (isu ? (size_t)P.HF : gstride) +
+                                      (isu ? lane_off : goff));
       }
     }
     for (int j = 0; j < items; j += DGNN_FAST_U) {
@@ -735,11 +748,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           if (it + DGNN_FAST_U < items) {
             const unsigned nv = (unsigned)uniform_i32((int)stream[it + DGNN_FAST_U]);
             const bool isu = (nv & DGNN_BWD_UFLAG) != 0u;
-            if (active) ring[i] = *(const vec_t *)((isu ? P.in_feat : P.grad) + (size_t)(nv & DGNN_BWD_IDMASK) * (isu ? (size_t)P.HF : gstride) +
-                                                   (isu ? lane_off : goff));
+            if (active) ring[i] = V::load((isu ? P.in_feat : P.grad) + (size_t)(nv & DGNN_BWD_IDMASK) * (isu ? (size_t)P.HF : gstride) +
+                                          (isu ? lane_off : goff));
           }
           if (v & DGNN_BWD_UFLAG) {
-            u = x;
+            u = dot_operand<VEC>(x, ln.dup);
             ++k;
           } else {
             const int p = it - (k + 1);
@@ -756,11 +769,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
             if (v & DGNN_BWD_END) {
               const int dst = uniform_i32(dq[k]);
               if (dst >= 0) {
-                if (active) *(vec_t *)(P.grad_feat + (size_t)dst * P.HF + lane_off) = acc;
+                if (active) V::store(P.grad_feat + (size_t)dst * P.HF + lane_off, acc);
                 if (BMODE == BWD_GAT && head_leader) P.grad_attn_col[(size_t)dst * H + head] = dsum;
               } else {
                 float *sp = P.slots + (size_t)(-(dst + 1)) * P.slot_stride;
-                if (active) *(vec_t *)(sp + lane_off) = acc;
+                if (active) V::store(sp + lane_off, acc);
                 if (BMODE == BWD_GAT && head_leader) sp[P.HF + head] = dsum;
               }
               acc = V::zero();
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P, int phase
 #pragma unroll
         for (int j = 0; j < FB; ++j) {
           const float *sp = slot_of(min(i0 + j, cnt - 1));
-          v[j] = *(const vec_t *)(sp + ln.off);
+          v[j] = V::load(sp + ln.off);
           d[j] = want_d ? sp[P.HF + ln.head] : 0.f;
         }
 #pragma unroll
@@ -872,11 +885,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_fixup(BwdParams P, int phase
     if (phase == 0) {
       float *sp = slot_of(0);
       if (ln.active) {
-        *(vec_t *)(sp + ln.off) = acc;
+        V::store(sp + ln.off, acc);
         if (ln.leader && want_d) sp[P.HF + ln.head] = dsum;
       }
     } else if (ln.active) {
-      *(vec_t *)(P.grad_feat + (size_t)c * P.HF + ln.off) = acc;
+      V::store(P.grad_feat + (size_t)c * P.HF + ln.off, acc);
       if (ln.leader && P.grad_attn_col != nullptr) P.grad_attn_col[(size_t)c * H + ln.head] = dsum;
     }
   }

@@ -89,12 +89,17 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   P.slot_neg = w.slot_neg;
   P.task_row0 = (int *)((char *)workspace + w.off_rows);
   P.slots = (float *)((char *)workspace + w.off_slots);
-  const bool vec4 = (P.F % 4 == 0) && aligned16(P.in_feat) && aligned16(P.out);
+  // float4 lanes for every width of at least four floats: rows need no 16-byte alignment (common.hpp:
+  // ld4u), so odd widths (1 x 47, 4 x 41 ...) and misaligned tensors take the same kernels.  The
+  // summed store (GMM layer) keeps its aligned float4 lanes: gmm_sum_shape() admits F % 4 == 0 only.
+  const bool vec4 = P.F >= 4 && (!P.sum_heads || (P.F % 4 == 0 && aligned16(P.out)));
   const bool attn_ok = (MODE != MODE_GAT) || P.H != 4 || aligned16(P.attn_col);
   if (!attn_ok) return DGNN_ERR_ALIGNMENT;
   // the negative-score pair exists for float4 rows only (the caller falls back to the edge-gradient path)
-  if (neg && !(vec4 && aligned16(P.out_neg) && aligned16(P.a_neg))) return DGNN_ERR_UNSUPPORTED;
-  P.rowv = vec4 ? P.HF / 4 : P.HF;
+  if (neg && !(vec4 && aligned16(P.a_neg))) return DGNN_ERR_UNSUPPORTED;
+  P.vec4 = vec4 ? 1 : 0;
+  P.spf = vec4 ? (P.F + 3) / 4 : P.F;
+  P.rowv = P.H * P.spf;
   // rows narrower than one wave of float4 slots are bound by instructions per edge, not bandwidth
   // (the STEADY instantiation of the kernel; DGNN_FWD_STEADY=0 switches it off for A/B runs)
   P.steady = (vec4 && P.rowv < DGNN_WAVE && env_int("DGNN_FWD_STEADY", 1) != 0) ? 1 : 0;
@@ -230,10 +235,13 @@ int bwd_pack_lanes(bool steady, int h, int fv) {
   while (s < h * fv) s <<= 1;
   return s;
 }
+// floats per lane of the backward's lane map: float4 lanes for every width of at least four floats
+// (rows need no 16-byte alignment: common.hpp ld4u), scalar lanes below
+int bwd_vec(int f) { return f >= 4 ? 4 : 1; }
 bool bwd_fast_shape(int m, int n, int h, int f) {
   if (force_generic() || h > 8 || m >= (1 << 30) || n >= (1 << 30)) return false;
   if (f > 256) return false;
-  return bwd_lanes_per_head(f, f % 4 == 0 ? 4 : 1) <= DGNN_WAVE;   // one head fits one lane pass
+  return bwd_lanes_per_head(f, bwd_vec(f)) <= DGNN_WAVE;   // one head fits one lane pass
 }
 
 BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recompute) {
@@ -498,7 +506,7 @@ int dgnn_gat_row_stats(int m, int h, int f, float negative_slope, const float *a
   if (!attn_row || !edge_max || !edge_sum || !grad || !out_feat || !row_stat) return DGNN_ERR_BAD_ARG;
   if ((out_neg == nullptr) != (a_neg == nullptr) || (out_neg != nullptr && grad_attn_row == nullptr))
     return DGNN_ERR_BAD_ARG;
-  const int vec = (f % 4 == 0 && aligned16(grad) && aligned16(out_feat) && (out_neg == nullptr || aligned16(out_neg))) ? 4 : 1;
+  const int vec = bwd_vec(f);
   if (h > 8 || bwd_lanes_per_head(f, vec) > DGNN_WAVE || !aligned16(row_stat)) return DGNN_ERR_UNSUPPORTED;
   if (out_neg != nullptr && vec != 4) return DGNN_ERR_UNSUPPORTED;
   BwdParams P = {};
@@ -576,16 +584,13 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     if (rc) return rc;
     out = tmp;
   }
-  const int vec = (f % 4 == 0) ? 4 : 1;
-  // float4 row slices need 16-byte aligned tensors; H = 4 moves attn_col as float4 in any case
-  bool fast = w.fast && (h != 4 || aligned16(attn_col)) &&
-              (vec == 1 || (aligned16(in_feat) && aligned16(grad) && aligned16(grad_feat) &&
-                            (out == nullptr || aligned16(out))));
+  const int vec = bwd_vec(f);
+  // H = 4 moves attn_col as float4; the feature rows need no 16-byte alignment (common.hpp: ld4u)
+  bool fast = w.fast && (h != 4 || aligned16(attn_col));
   if (packed != nullptr && !(fast && aligned16(packed))) return DGNN_ERR_UNSUPPORTED;
   // grad_attn_row from the forward's negative-score pair (row pass) instead of the [nnz,h] edge
   // gradients: the fast float4 kernels with the unpacked per-row inputs
-  const bool neg = fast && vec == 4 && out_neg != nullptr && packed == nullptr && m > 0 && aligned16(out_neg) &&
-                   !no_row_grad;
+  const bool neg = fast && vec == 4 && out_neg != nullptr && packed == nullptr && m > 0 && !no_row_grad;
   if (rng.on && !fast) return DGNN_ERR_UNSUPPORTED;   // the wave-per-column kernel reads a materialised mask
   if (no_row_grad && !fast && m > 0) return DGNN_ERR_UNSUPPORTED;
   if (fast) {
@@ -593,7 +598,7 @@ static int gat_backward_impl(int m, int n, int nnz, int h, int f, float negative
     P.n = n; P.m = m; P.nnz = nnz; P.H = h; P.F = f; P.HF = h * f;
     P.L = w.L; P.T = w.T; P.vec = vec; P.fv = bwd_lanes_per_head(f, vec); P.slot_stride = w.slot_stride;
     P.hpp = DGNN_WAVE / P.fv;
-    P.steady = (vec == 4 && h * f / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
+    P.steady = (vec == 4 && h * ((f + 3) / 4) < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
     P.pack_s = bwd_pack_lanes(P.steady != 0, h, P.fv);
     P.fv_const = env_int("DGNN_BWD_PACK_CONST", 1);
     const int hc = bwd_heads_padded(h);
@@ -853,7 +858,7 @@ int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *c
 // sequence, whose kernels hold several slices per lane, is faster (measured on the Reddit shape).
 static bool gmm_backward_fused_shape(int nodes, int kernels, int embed) {
   if (!bwd_fast_shape(nodes, nodes, kernels, embed)) return false;
-  return kernels * bwd_lanes_per_head(embed, embed % 4 == 0 ? 4 : 1) <= DGNN_WAVE;
+  return kernels * bwd_lanes_per_head(embed, bwd_vec(embed)) <= DGNN_WAVE;
 }
 
 // The summed-gradient form with the kernels in registers (k_bwd_col_gather, run_hreg): float4 rows of
@@ -890,9 +895,7 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
   if (nnz > 0 && (!row_ind || !permute || !node_feat || !pseudo || !grad || !grad_gauss))
     return DGNN_ERR_BAD_ARG;
   if (!gmm_backward_fused_shape(nodes, kernels, embed)) return DGNN_ERR_UNSUPPORTED;
-  const int vec = (embed % 4 == 0) ? 4 : 1;
-  if (vec == 4 && !(aligned16(node_feat) && aligned16(grad) && aligned16(grad_node_feat)))
-    return DGNN_ERR_UNSUPPORTED;
+  const int vec = bwd_vec(embed);
   const size_t need = dgnn_gmm_backward_workspace_bytes(nodes, nnz, kernels, embed);
   if (!workspace || workspace_bytes < need) return DGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -901,7 +904,7 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
   const int hc = bwd_heads_padded(kernels);
   P.L = bwd_group_size(hc, nnz, narrow_rows(kernels, embed));
   P.vec = vec; P.fv = bwd_lanes_per_head(embed, vec); P.hpp = DGNN_WAVE / P.fv;
-  P.steady = (vec == 4 && kernels * embed / 4 < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
+  P.steady = (vec == 4 && kernels * ((embed + 3) / 4) < DGNN_WAVE && env_int("DGNN_BWD_STEADY", 1) != 0) ? 1 : 0;
   P.pack_s = bwd_pack_lanes(P.steady != 0, kernels, P.fv);
   P.hreg = (grad_sum && vec == 4 && P.steady && gmm_hreg_shape(kernels, embed)) ? 1 : 0;
   if (P.hreg) {

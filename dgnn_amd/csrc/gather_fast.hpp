@@ -41,7 +41,11 @@ enum { MODE_GAT = 0, MODE_VAL = 1, MODE_GMM = 2 };
 
 struct GatherParams {
   int m, nnz, H, F, HF, L, T;        // rows, edges, heads, feat, H*F, group size, #groups
-  int rowv;                          // HF / VEC : vector slots per feature row
+  int rowv;                          // vector slots per feature row: H * spf
+  int vec4;                          // != 0: float4 lanes (F >= 4), else scalar lanes
+  int spf;                           // vector slots per head: ceil(F / 4) for float4 lanes (any F >= 4: the last
+                                     // slot of an F that is no multiple of four overlaps its predecessor,
+                                     // common.hpp slot4_off), F for scalar lanes
   int slot_stride;                   // floats per partial slot (HF + 2H rounded up to 4)
   int dim;                           // GMM pseudo dimension
   int sum_heads;                     // != 0: out is [m,F] = the sum over the H heads / kernels (GMMConv layer:
@@ -85,7 +89,7 @@ static inline int shrink_group_for_small_graphs(int L, int nnz, int min_L) {
 // Rows below 64 float4 slots (1 x 64, 4 x 16, 8 x 8 ...) are bound by latency and instruction
 // issue, not bandwidth: they want occupancy, i.e. at most ~6 KiB of LDS per wave (swept on the
 // products and Reddit shapes, tools/sweep_narrow.sh: 4 x 16 forward 6.9 -> 4.5 ms with 256).
-static inline bool narrow_rows(int H, int F) { return F % 4 == 0 && H * F / 4 < DGNN_WAVE; }
+static inline bool narrow_rows(int H, int F) { return F >= 4 && H * ((F + 3) / 4) < DGNN_WAVE; }
 // Tuning override (multiples of 16): DGNN_FWD_L.
 static inline int fast_group_size(int H, int nnz, bool narrow = false) {
   int dflt = H <= 4 ? 512 : 256;
@@ -149,6 +153,9 @@ template <>
 struct VecT<4> {
   using type = float4;
   static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  // feature rows: 16 bytes per lane at any dword-aligned address (common.hpp: ld4u)
+  static __device__ __forceinline__ float4 load(const float *p) { return ld4u(p); }
+  static __device__ __forceinline__ void store(float *p, const float4 &v) { st4u(p, v); }
   static __device__ __forceinline__ void fma(float4 &a, float w, const float4 &x) {
     a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);
   }
@@ -160,6 +167,8 @@ template <>
 struct VecT<1> {
   using type = float;
   static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ float load(const float *p) { return *p; }
+  static __device__ __forceinline__ void store(float *p, const float &v) { *p = v; }
   static __device__ __forceinline__ void fma(float &a, float w, const float &x) { a = fmaf(w, x, a); }
   static __device__ __forceinline__ void scale_add(float &a, float s, const float &x) { a = fmaf(s, x, a); }
   static __device__ __forceinline__ void mul(float &a, float s) { a *= s; }
@@ -216,6 +225,23 @@ __device__ __forceinline__ void acc_edge(typename VecT<VEC>::type &acc, typename
     an += wn;
   } else {
     VecT<VEC>::fma(acc, w, x);
+  }
+}
+
+// Vector slot -> (head, float offset inside the feature row).  Float4 lanes: head h owns slots
+// [h*spf, (h+1)*spf), slot q of a head the floats slot4_off(q, F) .. +3 of it (for F % 4 == 0 this
+// is slot * 4); scalar lanes: slot = float.
+template <int VEC>
+__device__ __forceinline__ void fwd_slot_map(const GatherParams &P, int vslot, int &head, size_t &off, bool &first) {
+  if (VEC == 4) {
+    head = vslot / P.spf;
+    const int q = vslot - head * P.spf;
+    off = (size_t)head * P.F + (size_t)slot4_off(q, P.F);
+    first = q == 0;
+  } else {
+    head = vslot / P.F;
+    off = (size_t)vslot;
+    first = vslot == head * P.F;
   }
 }
 
@@ -684,12 +710,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       const int S = P.pack_s;
       const int g = lane / S, sl = lane % S;
       const bool active = sl < P.rowv;
-      const int head = active ? (sl * 4) / P.F : 0;
-      const size_t lane_off = (size_t)(active ? sl : 0) * 4;
+      int head;
+      size_t lane_off;
+      bool first_of_head;
+      fwd_slot_map<4>(P, active ? sl : 0, head, lane_off, first_of_head);
       const float *wbase = sc + head;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accn = acc;
       float an = 0.f;
-      const bool an_leader = active && g == 0 && (sl * 4) % P.F == 0;
+      const bool an_leader = active && g == 0 && first_of_head;
       float4 ring[DGNN_FAST_U];
       float wring[DGNN_FAST_U];
       int q = 0;
@@ -700,7 +728,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         const int pe = p0 + (live ? g : 0);
         const unsigned c = cidx[pe] & ~DGNN_ROWEND;
         w = live ? wbase[(size_t)pe * H] : 0.f;
-        x = *(const float4 *)(P.in_feat + (size_t)c * P.HF + lane_off);
+        x = ld4u(P.in_feat + (size_t)c * P.HF + lane_off);
       };
       auto consume = [&](const float4 &x, float w, int j) {
         acc_edge<NEG, 4>(acc, accn, an, w, x);
@@ -724,11 +752,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             store_row_summed(P, d, active && g == 0, head, lane_off, acc);
           } else {
             float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
-            if (active && g == 0) *(float4 *)(dst + lane_off) = acc;
+            if (active && g == 0) st4u(dst + lane_off, acc);
             if constexpr (NEG) {
               float *dn = (d >= 0) ? P.out_neg + (size_t)d * P.HF
                                    : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
-              if (active && g == 0) *(float4 *)(dn + lane_off) = accn;
+              if (active && g == 0) st4u(dn + lane_off, accn);
               accn = make_float4(0.f, 0.f, 0.f, 0.f);
               if (!an_in_b && an_leader) {
                 if (d >= 0) P.a_neg[(size_t)d * H + head] = an;
@@ -801,14 +829,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     for (int s = 0; s < NS; ++s) {
       const int vslot = fb * span + s * DGNN_WAVE + lane;
       active[s] = vslot < P.rowv;
-      const int head = active[s] ? (vslot * VEC) / P.F : 0;
-      lane_off[s] = (size_t)(active[s] ? vslot : 0) * VEC;
+      int head;
+      bool first_of_head;
+      fwd_slot_map<VEC>(P, active[s] ? vslot : 0, head, lane_off[s], first_of_head);
       wbase[s] = sc + head;
       acc[s] = V::zero();
       accn[s] = V::zero();
       an[s] = 0.f;
       an_head[s] = head;
-      an_leader[s] = active[s] && (vslot * VEC) % P.F == 0;
+      an_leader[s] = active[s] && first_of_head;
       if (s == 0) hd0 = head;
     }
     int q = 0;
@@ -831,7 +860,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
+          if (active[s]) V::store(dst + lane_off[s], acc[s]);
           acc[s] = V::zero();
         }
         if constexpr (NEG) {
@@ -839,7 +868,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                                : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
-            if (active[s]) *(vec_t *)(dn + lane_off[s]) = accn[s];
+            if (active[s]) V::store(dn + lane_off[s], accn[s]);
             accn[s] = V::zero();
             if (!an_in_b && an_leader[s]) {
               if (d >= 0) P.a_neg[(size_t)d * H + an_head[s]] = an[s];
@@ -866,7 +895,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         for (int s = 0; s < NS; ++s) {
           wslot[s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
           if (active[s] && !(skip0 && wslot[s] == 0.f))
-            slot[s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+            slot[s] = V::load(P.in_feat + (size_t)c * P.HF + lane_off[s]);
           else
             slot[s] = V::zero();
         }
@@ -886,7 +915,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           wring[k][s] = wbase[s][(size_t)k * H];
-          ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+          ring[k][s] = V::load(P.in_feat + (size_t)c * P.HF + lane_off[s]);
         }
         __builtin_amdgcn_sched_barrier(0);   // issue order = slot order (the waits count loads)
       }
@@ -904,7 +933,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
             wring[k][s] = wnext[s];
-            ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+            ring[k][s] = V::load(P.in_feat + (size_t)c * P.HF + lane_off[s]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -931,7 +960,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           for (int s = 0; s < NS; ++s) {
             wring[k][s] = wbase[s][(size_t)k * H];
             if (active[s] && !(skip0 && wring[k][s] == 0.f))
-              ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+              ring[k][s] = V::load(P.in_feat + (size_t)c * P.HF + lane_off[s]);
           }
         }
       }
@@ -954,7 +983,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
               for (int s = 0; s < NS; ++s) {
                 wring[k][s] = wbase[s][(size_t)(p + DGNN_FAST_U) * H];
                 if (active[s] && !(skip0 && wring[k][s] == 0.f))
-                  ring[k][s] = *(const vec_t *)(P.in_feat + (size_t)c * P.HF + lane_off[s]);
+                  ring[k][s] = V::load(P.in_feat + (size_t)c * P.HF + lane_off[s]);
                 else
                   ring[k][s] = V::zero();
               }
@@ -977,7 +1006,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                                       : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                  if (active[s]) *(vec_t *)(dst + lane_off[s]) = acc[s];
+                  if (active[s]) V::store(dst + lane_off[s], acc[s]);
                   acc[s] = V::zero();
                 }
                 if constexpr (NEG) {
@@ -985,7 +1014,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
                                        : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
 #pragma unroll
                   for (int s = 0; s < NS; ++s) {
-                    if (active[s]) *(vec_t *)(dn + lane_off[s]) = accn[s];
+                    if (active[s]) V::store(dn + lane_off[s], accn[s]);
                     accn[s] = V::zero();
                     if (!an_in_b && an_leader[s]) {
                       if (d >= 0) P.a_neg[(size_t)d * H + an_head[s]] = an[s];
@@ -1040,9 +1069,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
   const int t_last = (re - 1) / L;
   // piece i = 0 is the tail slot of group t0-1, pieces 1.. are the head slots of groups t0..t_last
   const int npieces = t_last - t0 + 2;
-  const bool vec4 = (P.F % 4 == 0) && ((((uintptr_t)P.out) & 15u) == 0);
-  const int vw = vec4 ? 4 : 1;
-  const int nslots = P.HF / vw;
+  const bool vec4 = P.vec4 != 0;
+  const int nslots = P.rowv;
   const bool two_level = npieces > DGNN_FIX_C && nslots <= DGNN_WAVE;
   int first = 0, cnt = npieces, stride = 1;
   if (phase == 0) {
@@ -1071,8 +1099,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
   for (int fb = 0; fb * DGNN_WAVE < nslots; ++fb) {
     const int vs = fb * DGNN_WAVE + lane;
     const bool active = vs < nslots;
-    const int fid = (active ? vs : 0) * vw;
-    const int head = fid / P.F;
+    int head;
+    size_t slot_off;
+    bool first_of_head;
+    if (vec4) fwd_slot_map<4>(P, active ? vs : 0, head, slot_off, first_of_head);
+    else fwd_slot_map<1>(P, active ? vs : 0, head, slot_off, first_of_head);
+    const int fid = (int)slot_off;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // Pieces are loaded in batches whose loads are issued together, the arithmetic then runs over
     // them in piece order (same sums as one piece at a time).  Nearly every cut row has two pieces:
@@ -1104,11 +1136,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
             const float *sp = slot_of(min(i0 + j, cnt - 1));
             m[j] = sp[P.HF + head];
             sm[j] = sp[P.HF + H + head];
-            if (vec4) v[j] = *(const float4 *)(sp + fid);
+            if (vec4) v[j] = ld4u(sp + fid);
             else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
             if (neg) {
               sa[j] = sp[P.HF + 2 * H + head];
-              vn[j] = *(const float4 *)(sp + P.slot_neg + fid);
+              vn[j] = ld4u(sp + P.slot_neg + fid);
             }
           }
           if (one) {
@@ -1137,10 +1169,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
         // stored depend on them)
         float *sp = slot_of(0);
         if (active) {
-          if (vec4) *(float4 *)(sp + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          if (vec4) st4u(sp + fid, make_float4(acc[0], acc[1], acc[2], acc[3]));
           else sp[fid] = acc[0];
-          if (neg) *(float4 *)(sp + P.slot_neg + fid) = make_float4(nacc[0], nacc[1], nacc[2], nacc[3]);
-          if (fid == head * P.F) {
+          if (neg) st4u(sp + P.slot_neg + fid, make_float4(nacc[0], nacc[1], nacc[2], nacc[3]));
+          if (first_of_head) {
             sp[P.HF + head] = M;
             sp[P.HF + H + head] = S;
             if (neg) sp[P.HF + 2 * H + head] = an;
@@ -1149,16 +1181,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
         continue;
       }
       if (neg && active) {
-        *(float4 *)(P.out_neg + (size_t)r * P.HF + fid) = make_float4(nacc[0] / S, nacc[1] / S, nacc[2] / S, nacc[3] / S);
-        if (fid == head * P.F) P.a_neg[(size_t)r * H + head] = an / S;
+        st4u(P.out_neg + (size_t)r * P.HF + fid, make_float4(nacc[0] / S, nacc[1] / S, nacc[2] / S, nacc[3] / S));
+        if (first_of_head) P.a_neg[(size_t)r * H + head] = an / S;
       }
       if (active) {
         if (vec4)
-          *(float4 *)(P.out + (size_t)r * P.HF + fid) =
-              make_float4(acc[0] / S, acc[1] / S, acc[2] / S, acc[3] / S);
+          st4u(P.out + (size_t)r * P.HF + fid, make_float4(acc[0] / S, acc[1] / S, acc[2] / S, acc[3] / S));
         else
           P.out[(size_t)r * P.HF + fid] = acc[0] / S;
-        if (P.edge_max != nullptr && fid == head * P.F) {
+        if (P.edge_max != nullptr && first_of_head) {
           P.edge_max[(size_t)r * H + head] = M;
           P.edge_sum[(size_t)r * H + head] = S;
         }
@@ -1171,7 +1202,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
 #pragma unroll
           for (int j = 0; j < FB; ++j) {
             const float *sp = slot_of(min(i0 + j, cnt - 1));
-            if (vec4) v[j] = *(const float4 *)(sp + fid);
+            if (vec4) v[j] = ld4u(sp + fid);
             else v[j] = make_float4(sp[fid], 0.f, 0.f, 0.f);
           }
 #pragma unroll
@@ -1184,7 +1215,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
       if (!final_pass) {
         float *sp = slot_of(0);
         if (active) {
-          if (vec4) *(float4 *)(sp + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          if (vec4) st4u(sp + fid, make_float4(acc[0], acc[1], acc[2], acc[3]));
           else sp[fid] = acc[0];
         }
         continue;
@@ -1193,7 +1224,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
         store_row_summed(P, r, active, head, (size_t)(fid - head * P.F), make_float4(acc[0], acc[1], acc[2], acc[3]));
       } else if (active) {
         if (vec4)
-          *(float4 *)(P.out + (size_t)r * P.HF + fid) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          st4u(P.out + (size_t)r * P.HF + fid, make_float4(acc[0], acc[1], acc[2], acc[3]));
         else
           P.out[(size_t)r * P.HF + fid] = acc[0];
       }

@@ -54,12 +54,20 @@ struct SdVec<4> {
   static __device__ __forceinline__ float dot(const T &x, const T &u) {
     return fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, x.w * u.w)));
   }
+  // rows of any width >= 4 floats at any dword alignment; a head's last slot may repeat floats of
+  // its predecessor, which the ROW operand drops before the dot (common.hpp: ld4u, slot4_*)
+  static __device__ __forceinline__ T load(const float *p) { return ld4u(p); }
+  static __device__ __forceinline__ int off(int q, int F) { return slot4_off(q, F); }
+  static __device__ __forceinline__ T row_operand(const T &v, int q, int F) { return slot4_mask(v, slot4_dup(q, F)); }
 };
 template <>
 struct SdVec<1> {
   using T = float;
   static __device__ __forceinline__ T zero() { return 0.f; }
   static __device__ __forceinline__ float dot(const T &x, const T &u) { return x * u; }
+  static __device__ __forceinline__ T load(const float *p) { return *p; }
+  static __device__ __forceinline__ int off(int q, int) { return q; }
+  static __device__ __forceinline__ T row_operand(const T &v, int, int) { return v; }
 };
 
 // NS = head slices per lane: one walk of the stream serves hpp*NS heads.
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H
       const int hd = hb + s * hpp + lane / fv;
       active[s] = hd < H && q * VEC < F;
       head[s] = active[s] ? hd : 0;
-      lane_off[s] = active[s] ? (size_t)hd * F + (size_t)q * VEC : 0;
+      lane_off[s] = active[s] ? (size_t)hd * F + (size_t)V::off(q, F) : 0;
       head_leader[s] = active[s] && q == 0;
       u[s] = V::zero();
     }
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H
         const float *base = ((sv & DGNN_SDDMM_UFLAG) ? A : B) + (size_t)(sv & 0x7fffffffu) * HF;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          if (active[s]) ring[i][s] = *(const vec_t *)(base + lane_off[s]);
+          if (active[s]) ring[i][s] = V::load(base + lane_off[s]);
       }
     }
     for (int j = 0; j < items; j += DGNN_SDDMM_U) {
@@ -174,11 +182,11 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H
             const float *base = ((nv & DGNN_SDDMM_UFLAG) ? A : B) + (size_t)(nv & 0x7fffffffu) * HF;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-              if (active[s]) ring[i][s] = *(const vec_t *)(base + lane_off[s]);
+              if (active[s]) ring[i][s] = V::load(base + lane_off[s]);
           }
           if (sv & DGNN_SDDMM_UFLAG) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) u[s] = x[s];
+            for (int s = 0; s < NS; ++s) u[s] = V::row_operand(x[s], q, F);
             ++k;
           } else {
             const int p = it - (k + 1);
@@ -634,7 +642,8 @@ int dgnn_mhsddmm(int v, int f, int h, int nnz, const int *row_ptr, const int *co
   const int hf = h * f;
   const char *fg = getenv("DGNN_FORCE_GENERIC");
   // lanes per head: power of two covering ceil(f / vec) lanes; a head must fit one lane pass
-  const int vec = (f % 4 == 0 && (((uintptr_t)grad | (uintptr_t)feature) & 15u) == 0) ? 4 : 1;
+  // float4 lanes for every width of at least four floats (rows need no 16-byte alignment: common.hpp ld4u)
+  const int vec = f >= 4 ? 4 : 1;
   int fv = 1;
   while (fv < (f + vec - 1) / vec) fv <<= 1;
   const bool fast = fv <= DGNN_WAVE && h <= 8 && v < (1 << 30) && !(fg && fg[0] == '1');

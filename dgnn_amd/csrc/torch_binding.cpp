@@ -185,7 +185,7 @@ std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, 
   // neg: also the negative-score pair [out_neg, a_neg] the backward turns into grad_attn_row
   // (appended to the list; two undefined tensors = None where the kernels have no such pair)
   Tensor out_neg, a_neg;
-  if (neg && d.m > 0 && d.f % 4 == 0) {
+  if (neg && d.m > 0 && d.f >= 4) {
     out_neg = out_f32(outs, 3, {d.m, d.h, d.f}, in_feat, "out_neg");
     a_neg = out_f32(outs, 4, {d.m, d.h}, in_feat, "a_neg");
   }
@@ -372,7 +372,7 @@ py::object gat_forward_seeded(const Tensor &attn_row, const Tensor &attn_col, co
   const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
   Tensor ws = workspace(nb, in_feat);
   Tensor out_neg, a_neg;
-  if (neg && d.m > 0 && d.f % 4 == 0) {
+  if (neg && d.m > 0 && d.f >= 4) {
     out_neg = new_f32({d.m, d.h, d.f}, in_feat);
     a_neg = new_f32({d.m, d.h}, in_feat);
   }
@@ -456,7 +456,7 @@ py::object gat_forward_seeded_dev(const Tensor &attn_row, const Tensor &attn_col
   const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
   Tensor ws = workspace(nb, in_feat);
   Tensor out_neg, a_neg;
-  if (neg && d.m > 0 && d.f % 4 == 0) {
+  if (neg && d.m > 0 && d.f >= 4) {
     out_neg = new_f32({d.m, d.h, d.f}, in_feat);
     a_neg = new_f32({d.m, d.h}, in_feat);
   }

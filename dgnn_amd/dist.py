@@ -496,7 +496,7 @@ class PartitionedGAT:
             # a shape agrees on it over the group (_agree_on_pair) and later steps reuse the answer.
             key = (h, in_feat_loc.size(-1))
             agreed = self._pair_agreed.get(key)
-            want_neg = getattr(self.ops, "supports_neg", False) and in_feat_loc.size(-1) % 4 == 0 and agreed is not False
+            want_neg = getattr(self.ops, "supports_neg", False) and in_feat_loc.size(-1) >= 4 and agreed is not False
             out_neg = torch.empty_like(out) if want_neg else None
             a_neg = torch.empty_like(emax) if want_neg else None
             streams = self._chunk_streams(in_feat_loc.device)

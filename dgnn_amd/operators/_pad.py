@@ -1,4 +1,4 @@
-"""Feature rows padded to a multiple of four floats for the autograd operators."""
+"""Feature rows narrower than four floats padded to four for the autograd operators."""
 import torch
 
 # Below this many rows a call is bound by launch latency, not by how its lanes move the rows:
@@ -7,16 +7,16 @@ PAD_MIN_ROWS = 1 << 15
 
 
 def pad4(x):
-    """[n,h,f] -> the same rows zero-padded to the next multiple of four features.  A row of
-    4 x 41 or 1 x 47 floats is not 16-byte aligned, which leaves the kernels scalar lanes (one
-    head per walk over the edges, and the one-pass backward out of range for three 41-wide
-    kernels); padded to 4 x 44 / 1 x 48 the same rows move as float4 in one walk.  Zero features
+    """[n,h,f] -> the same rows zero-padded to four features when f < 4, else unchanged.  Since
+    round 3 the kernels move every row of at least four floats as float4 lanes whatever its
+    width or alignment (16-byte global accesses at dword-aligned addresses run at full rate on
+    gfx950: csrc/common.hpp ld4u, tools/probe_unaligned.hip), so 4 x 41 or 1 x 47 need no padded
+    copies any more; only rows of one to three floats would be left scalar lanes.  Zero features
     gather, accumulate and dot to zero, so the first f features are unchanged."""
     f = x.size(2)
-    fp = (f + 3) // 4 * 4
-    if fp == f or x.size(0) < PAD_MIN_ROWS:
+    if f >= 4 or x.size(0) < PAD_MIN_ROWS:
         return x
-    return torch.nn.functional.pad(x, (0, fp - f))
+    return torch.nn.functional.pad(x, (0, 4 - f))
 
 
 def pad_to(x, width):

@@ -184,7 +184,7 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
         assert runner._neg is not None, "the stand-in offers the pair: the runner must take the owner-local path"
     if mode == "cpunegmix" and runner.mode == "halo" and world > 1:
         assert runner._neg is None, "one rank lacks the pair: NO rank may take the owner-local path"
-    if mode in ("gpu", "nccl") and runner.mode == "halo" and f % 4 == 0 and h <= 8:
+    if mode in ("gpu", "nccl") and runner.mode == "halo" and f >= 4 and h <= 8:
         assert runner._neg is not None, "float4 rows: the HIP forward must produce the pair on every rank"
     if mode in ("cpuneg", "cpunegmix", "gpu", "nccl"):      # a second step takes the remembered decision
         out2 = runner.forward(x_loc, t(attn_row[lo:hi]), t(attn_col[lo:hi]), 0.2)

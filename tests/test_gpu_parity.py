@@ -126,7 +126,8 @@ def test_gat_every_group_size(nat, name, fwd_l, bwd_l, h, f, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["deg_edges", "powerlaw256", "rmat4k"])
-@pytest.mark.parametrize("h,f", [(4, 64), (1, 64), (4, 16), (8, 8), (2, 100), (8, 64), (4, 128), (3, 20)])
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 64), (4, 16), (8, 8), (2, 100), (8, 64), (4, 128), (3, 20),
+                                 (1, 47), (4, 41), (1, 7), (3, 6), (8, 9), (2, 130), (5, 5)])
 @pytest.mark.parametrize("p", [0.0, 0.5])
 @pytest.mark.parametrize("fwd_l", [0, 64])
 def test_gat_negative_score_pair_replaces_the_edge_gradient_round_trip(nat, name, h, f, p, fwd_l, monkeypatch):
@@ -316,14 +317,17 @@ def test_gat_fuzz_hub_rows_and_columns_merged_in_two_levels(nat, seed, monkeypat
 
 
 def test_gat_negative_score_pair_shapes_without_it(nat):
-    """Rows that are not float4 (f % 4 != 0) and more than eight heads have no pair: neg=True
-    returns None for both and the backward works as before."""
+    """Rows narrower than four floats and more than eight heads have no pair: neg=True returns
+    None for both and the backward works as before.  Every other width has it since round 3 (float4
+    lanes at any dword alignment): 1 x 47 and 4 x 41 are checked against the oracle in
+    test_gat_negative_score_pair_replaces_the_edge_gradient_round_trip."""
     g = GRAPHS["powerlaw256"]
-    for h, f in ((1, 47), (9, 8)):
+    for h, f in ((1, 3), (9, 8), (1, 47), (4, 41), (3, 6)):
         in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=2)
         G = gdev(g)
         res = nat["gat"].gat_forward(dev(attn_row), dev(attn_col), G["row_ptr"], G["col_ind"], 0.2, dev(in_feat), 0.0, neg=True)
-        assert len(res) == 6 and res[4] is None and res[5] is None
+        assert len(res) == 6
+        assert (res[4] is not None and res[5] is not None) == (f >= 4 and h <= 8), (h, f)
 
 
 def test_gat_caller_provided_outputs(nat):
@@ -438,7 +442,9 @@ def test_gat_forward_tb_rejects_a_malformed_tile_list(nat):
 
 @pytest.fixture(params=[0, 1 << 30], ids=["padded", "as-is"])
 def pad_rows(request, monkeypatch):
-    """Odd widths run zero-padded above PAD_MIN_ROWS rows (operators/_pad.py): both ways here."""
+    """Rows narrower than four floats run zero-padded above PAD_MIN_ROWS rows (operators/_pad.py): both
+    ways here.  (Until round 2 every width that is not a multiple of four was padded; those now take
+    the float4 lanes as they are.)"""
     import dgnn_amd.operators._pad as pad
     monkeypatch.setattr(pad, "PAD_MIN_ROWS", request.param)
     return request.param
@@ -627,7 +633,7 @@ def test_gmm(nat, name, k, d, f):
     grad = rng.standard_normal((g["n"], k, f)).astype(np.float32)
     fused = nat["gmm"].gmm_backward_fused(G["col_ptr"], G["row_ind"], G["permute"], dev(node_feat), dev(pseudo),
                                           dev(mu), dev(inv_sigma), dev(grad))
-    if k * (1 << int(np.ceil(np.log2(max(1, -(-f // (4 if f % 4 == 0 else 1)))))) ) > 64:
+    if k * (1 << int(np.ceil(np.log2(max(1, -(-f // (4 if f >= 4 else 1)))))) ) > 64:
         assert fused is None, "several lane passes: the caller keeps the three-call sequence"
         return
     assert fused is not None
@@ -1268,3 +1274,50 @@ def test_gat_forward_is_independent_of_the_group_size(nat, name, group, monkeypa
     assert_close(host(esum), s64, "edge_sum")
     _, m32, _ = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0, None)
     assert np.array_equal(host(emax), m32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 16), (8, 8), (4, 41), (1, 7), (2, 130)])
+def test_gat_feature_rows_at_any_dword_alignment(nat, h, f):
+    """The float4 lanes take feature rows at ANY 4-byte alignment (csrc/common.hpp: ld4u / st4u;
+    tools/probe_unaligned.hip): the same call with in_feat / grad / the outputs shifted by one, two
+    and three floats inside larger buffers returns the bits of the 16-byte-aligned call, and the
+    float before / after every output stays untouched."""
+    g = GRAPHS["rmat4k"]
+    G = gdev(g)
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=5)
+    ar, ac = dev(attn_row), dev(attn_col)
+    graph = (G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"])
+
+    def shifted(a, k):
+        buf = torch.full((a.size + 8,), 7.5, dtype=torch.float32, device=DEV)
+        view = buf[k:k + a.size].view(a.shape)
+        view.copy_(dev(a))
+        return buf, view
+
+    def run(k):
+        _, x = shifted(in_feat, k)
+        _, go = shifted(grad, k)
+        bo, out = shifted(np.zeros_like(in_feat), k)
+        bn, out_neg = shifted(np.zeros_like(in_feat), k)
+        bg, gf = shifted(np.zeros_like(in_feat), k)
+        res = nat["gat"].gat_forward(ar, ac, graph[0], graph[1], 0.2, x, 0.0, neg=True, out=(out, None, None, out_neg, None))
+        assert res[4] is not None and res[0].data_ptr() == out.data_ptr() and res[4].data_ptr() == out_neg.data_ptr()
+        got = nat["gat"].gat_backward(0.2, 0.0, *graph, res[1], res[2], res[3], x, ar, ac, go, out_feat=out,
+                                      out_neg=out_neg, a_neg=res[5], out=(gf, None, None))
+        assert got[0].data_ptr() == gf.data_ptr()
+        for b in (bo, bn, bg):      # nothing written outside the rows
+            assert bool((b[:k] == 7.5).all()) and bool((b[k + in_feat.size:] == 7.5).all())
+        return out.clone(), out_neg.clone(), res[5], gf.clone(), got[1], got[2]
+
+    base = run(0)
+    for k in (1, 2, 3):
+        for u, v in zip(base, run(k)):
+            assert torch.equal(u, v), f"shift {k}"
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, 0.0, g["row_ptr"], g["col_ind"], None, in_feat, attn_row, attn_col, grad)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2)
+    assert_close(host(base[0]), o64, "any alignment: out_feat", mass=m_out)
+    assert_close(host(base[3]), gf64, "any alignment: grad_feat", mass=m_gf)
+    assert_close(host(base[4]), gr64, "any alignment: grad_attn_row", mass=m_gr)
+    assert_close(host(base[5]), gc64, "any alignment: grad_attn_col", mass=m_gc)
