@@ -55,6 +55,34 @@ __device__ __forceinline__ float4 slot4_mask(float4 v, int dup) {
 // fused_gatconv_kernel.cu:13  LeakyRelu(x, s) = x > 0 ? x : x*s
 __device__ __forceinline__ float leaky_relu(float x, float s) { return (x > 0.f) ? x : x * s; }
 
+// ---- exp and divide of the softmax weights ------------------------------------------------
+// The weights are exp(e - max) / sum with e - max <= 0 (fused_gatconv_kernel.cu:75,102).  libm's
+// expf spends half of its ~15 instructions on overflow and denormal-input handling that cannot
+// occur here, and an IEEE divide is ~10; per (edge, head) of a narrow row that is a large share of
+// the kernel's vector instructions (8 x 8 forward: the softmax phase is ~60 % of them).  These forms
+// keep the accuracy class of the reference's own expf / division (each within ~1.5 ulp; CUDA's
+// expf is specified to 2 ulp): exp2 of the exactly reduced argument through v_exp_f32 + v_ldexp_f32,
+// and a multiply by v_rcp_f32 (1 ulp).  -DDGNN_EXACT_EXPDIV=1 builds with expf and '/' (A/B runs).
+__device__ __forceinline__ float exp_nonpos(float x) {
+#if defined(DGNN_EXACT_EXPDIV) && DGNN_EXACT_EXPDIV
+  return expf(x);
+#else
+  const float l2e_hi = 1.44269502162933349609375f;      // float(log2 e)
+  const float l2e_lo = 1.925963033500011e-08f;          // log2 e - float(log2 e)
+  const float n = rintf(x * l2e_hi);
+  float r = fmaf(x, l2e_hi, -n);                         // exact product, so |r| <= 0.5 + 2^-24 |n|
+  r = fmaf(x, l2e_lo, r);
+  return ldexpf(__builtin_amdgcn_exp2f(r), (int)n);      // x far below -150: the int conversion saturates, ldexp gives 0
+#endif
+}
+__device__ __forceinline__ float div_pos(float a, float b) {   // a / b for finite b > 0
+#if defined(DGNN_EXACT_EXPDIV) && DGNN_EXACT_EXPDIV
+  return a / b;
+#else
+  return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
+
 // ---- cross-lane reductions over the full 64-lane wave -----------------------------------
 // DPP row operations do the 16-lane part in the VALU (no LDS traffic); the four row results
 // are then combined through v_readlane.  All 64 lanes must be active.
@@ -74,6 +102,26 @@ struct OpSum {
 struct OpMax {
   __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
 };
+
+// max(v, v permuted inside its DPP row) as ONE v_max_f32 with a DPP source operand.  Written through
+// fmaxf the compiler cannot prove the permuted value is no signalling NaN and emits the move plus two
+// canonicalising v_max before the real one (four instructions per step; the 16-lane max of every head
+// of every softmax pass is four such steps).  The s_nop covers the two wait states a DPP read needs
+// after the VALU write of its source (the hazard recogniser does not look inside inline assembly).
+#define DGNN_DPP_MAX_STEP(name, ctrl)                                                                \
+  __device__ __forceinline__ float name(float v) {                                                   \
+    float r;                                                                                         \
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); \
+    return r;                                                                                        \
+  }
+DGNN_DPP_MAX_STEP(dpp_max_xor1, "quad_perm:[1,0,3,2]")
+DGNN_DPP_MAX_STEP(dpp_max_xor2, "quad_perm:[2,3,0,1]")
+DGNN_DPP_MAX_STEP(dpp_max_half_mirror, "row_half_mirror")
+DGNN_DPP_MAX_STEP(dpp_max_mirror, "row_mirror")
+#undef DGNN_DPP_MAX_STEP
+__device__ __forceinline__ float row16_reduce(float v, OpMax) {
+  return dpp_max_mirror(dpp_max_half_mirror(dpp_max_xor2(dpp_max_xor1(v))));
+}
 
 // Reduce inside each aligned group of 16 lanes (one DPP row); every lane of the row gets the result.
 template <class Op>
@@ -208,6 +256,24 @@ __device__ __forceinline__ float gmm_weight(int dim, const float *__restrict__ p
   }
   return (float)exp(-0.5 * (double)acc);
 }
+
+// ---- diagnostic build only (-DDGNN_PHASE_CLOCK, tools/phase_clock.sh): where do the waves of the
+// two gather kernels spend their time?  Each wave adds the shader-clock cycles between phase
+// boundaries to a device table read back with dgnn_debug_phase_cycles().  No stamp exists in the
+// product build.
+#ifdef DGNN_PHASE_CLOCK
+static __device__ unsigned long long g_phase_cycles[2][8];
+#define DGNN_PHASE_DECL() unsigned long long pc_t = __builtin_readcyclecounter()
+#define DGNN_PHASE_MARK(kernel, phase)                                                     \
+  do {                                                                                     \
+    const unsigned long long pc_n = __builtin_readcyclecounter();                          \
+    if (lane_id() == 0) atomicAdd(&g_phase_cycles[kernel][phase], pc_n - pc_t);            \
+    pc_t = pc_n;                                                                           \
+  } while (0)
+#else
+#define DGNN_PHASE_DECL() do { } while (0)
+#define DGNN_PHASE_MARK(kernel, phase) do { } while (0)
+#endif
 
 static inline int blocks_for_waves(long long n_waves) {
   return (int)((n_waves + DGNN_WAVES_PER_BLOCK - 1) / DGNN_WAVES_PER_BLOCK);

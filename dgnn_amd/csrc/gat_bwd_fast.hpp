@@ -232,8 +232,17 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
 // w_ik = Gaussian weight of edge i, and grad_gauss[permute[i],k] = <grad[r_i,k,:], node_feat[c,k,:]>.
 // STEADY: instantiation for narrow rows (fewer than 64 float4 slots), bound by instructions per
 // edge: adds an unguarded steady-state form of the gather stream (see gather_fast.hpp).
-template <int HC, int EPL, int VEC, int BMODE, bool STEADY>
+// PK (STEADY only) = which gather stream the instantiation holds, chosen by the host
+// (bwd_stream_kind in gather_bwd.hip) so that a kernel carries ONE stream instead of all of them:
+//   0  the one-entry-per-step streams (steady / guarded)
+//   1  the packed stream with run-time lane widths (and the GMM form with the kernels in registers)
+//   2, 4, 8, 16  the packed stream with PK lanes per head as a compile-time constant
+// Until round 3 every narrow kernel held all of these side by side and the register allocation was
+// the union of their lane constants: 102 VGPRs = four waves per SIMD at one head; one stream per
+// kernel takes 65 = seven waves, and these kernels are bound by the latencies a wave cannot hide.
+template <int HC, int EPL, int VEC, int BMODE, bool STEADY, int PK = 0>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
+  static_assert(PK == 0 || (STEADY && VEC == 4), "the packed streams exist in the narrow float4 instantiations only");
   using V = VecT<VEC>;
   using vec_t = typename V::type;
   extern __shared__ __align__(16) float lds_raw[];
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
+  DGNN_PHASE_DECL();
   if (BMODE == BWD_GAT) drop_resolve(P.rng);
   // (hreg: the stream holds HC U steps per column instead of one: (HC + 1) L words, bwd_lds_bytes)
   const size_t per_wave_floats = (size_t)L * HC * 2 + (size_t)L * 5 + ((BMODE == BWD_GMM && P.hreg) ? (size_t)L * (HC - 1) : 0);
@@ -257,6 +267,18 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
   const int cnt = e1 - e0;
 
   // ---------------------------------------------------------------- phase A: stage row data (registers)
+  // Wide rows fetch the packed row records here, ahead of the column directory whose latencies they
+  // overlap, and hold them in registers until the coefficient pass.  Narrow single-head rows fetch
+  // them in the coefficient pass itself (57 VGPRs = eight waves per SIMD instead of 65 = seven).
+  // With more heads the exposed latency costs more than the waves gained (measured, products shape,
+  // backward call without / with the early fetch: 8 x 8 5.36 / 5.12 ms, 2 x 64 8.04 / 7.14, 2 x 32
+  // 4.33 / 4.03), so those keep it.  DGNN_BWD_PREFETCH_NARROW=1 / 0 at build time forces it on / off
+  // for every narrow kernel (A/B runs).
+#ifdef DGNN_BWD_PREFETCH_NARROW
+  constexpr bool PREFETCH = !STEADY || DGNN_BWD_PREFETCH_NARROW != 0;
+#else
+  constexpr bool PREFETCH = !STEADY || HC >= 2;
+#endif
   int rid[EPL];
   float4 st[EPL][HC];
 #pragma unroll
@@ -269,13 +291,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     const int p = j * DGNN_WAVE + lane;
 #pragma unroll
     for (int h = 0; h < HC; ++h)
-      st[j][h] = (BMODE == BWD_GAT && p < cnt && h < H) ? P.rowstat[(size_t)rid[j] * H + h]
-                                                       : make_float4(0.f, 0.f, 1.f, 0.f);
+      st[j][h] = (PREFETCH && BMODE == BWD_GAT && p < cnt && h < H) ? P.rowstat[(size_t)rid[j] * H + h]
+                                                                   : make_float4(0.f, 0.f, 1.f, 0.f);
   }
 
+  DGNN_PHASE_MARK(1, 0);
   // ---------------------------------------------------------------- columns of the group
   int K = 0;   // non-empty columns seen so far
-  const bool packed = STEADY && P.pack_s > 0;
+  constexpr bool packed = PK != 0;       // the host launches PK != 0 exactly when P.pack_s > 0
   // packed stream: the load steps of the group in `stream`: per column one U step (the column's
   // own row: column id | UFLAG) followed by one step per (up to) G = 64 / pack_s consecutive
   // entries of that column: first entry (10 bits) | entries - 1 (4 bits) | DGNN_PACK_END on the
@@ -330,6 +353,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     }
   }
   wave_lds_sync();
+  DGNN_PHASE_MARK(1, 1);
 
   // ---------------------------------------------------------------- per-edge coefficients
 #pragma unroll
@@ -365,9 +389,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
 #pragma unroll
       for (int h = 0; h < HC; ++h) {
         if (h >= H) break;
-        const float4 s4 = st[j][h];                            // {attn_row, edge_max, edge_sum, S}
+        const float4 s4 = PREFETCH ? st[j][h] : P.rowstat[(size_t)rid[j] * H + h];   // {attn_row, edge_max, edge_sum, S}
         const float e = leaky_relu(s4.x + ac[h], P.slope);
-        const float a = expf(e - s4.y) / s4.z;                 // :747
+        const float a = div_pos(exp_nonpos(e - s4.y), s4.z);    // :747
         float w = a;
         if (drop) {
           const float mk = P.rng.on ? drop_uniform(P.rng, (unsigned long long)pos * H + h)
@@ -382,6 +406,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
     }
   }
   wave_lds_sync();
+  DGNN_PHASE_MARK(1, 2);
 
   // ---------------------------------------------------------------- pipelined gather stream
   const int items = cnt + K;
@@ -421,7 +446,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         // per entry instead of one per kernel, and (K = 3 x 64) four entries per step instead of one.
         // The column's own rows arrive as H consecutive U steps (kernel 0, 1, ...).
         bool ran_hreg = false;
-        if constexpr (BMODE == BWD_GMM) {
+        if constexpr (BMODE == BWD_GMM && PK == 1) {
           if (P.hreg) {
             ran_hreg = true;
             auto run_hreg = [&](auto scc) {
@@ -430,6 +455,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
               const bool act = qq * 4 < P.F;
               const size_t qoff = act ? (size_t)qq * 4 : 0;
               float4 uh[HC], acch[HC];
+              float4 ring[DGNN_PACK_U];
 #pragma unroll
               for (int h = 0; h < HC; ++h) uh[h] = acch[h] = make_float4(0.f, 0.f, 0.f, 0.f);
               int iu = 0, cu = 0;       // kernel of the next U step: issue side, consume side (wave-uniform)
@@ -489,29 +515,29 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
                 }
               };
               int j = 0;
-              if (nsteps >= 2 * DGNN_FAST_U) {
+              if (nsteps >= 2 * DGNN_PACK_U) {
 #pragma unroll
-                for (int i = 0; i < DGNN_FAST_U; ++i) {
+                for (int i = 0; i < DGNN_PACK_U; ++i) {
                   issue(i, ring[i]);
                   __builtin_amdgcn_sched_barrier(0);
                 }
-                for (; j + 2 * DGNN_FAST_U <= nsteps; j += DGNN_FAST_U) {
+                for (; j + 2 * DGNN_PACK_U <= nsteps; j += DGNN_PACK_U) {
 #pragma unroll
-                  for (int i = 0; i < DGNN_FAST_U; ++i) {
+                  for (int i = 0; i < DGNN_PACK_U; ++i) {
                     consume(ring[i], j + i);
-                    issue(j + i + DGNN_FAST_U, ring[i]);
+                    issue(j + i + DGNN_PACK_U, ring[i]);
                     __builtin_amdgcn_sched_barrier(0);
                   }
                 }
 #pragma unroll
-                for (int i = 0; i < DGNN_FAST_U; ++i) {
+                for (int i = 0; i < DGNN_PACK_U; ++i) {
                   const float4 x = ring[i];
-                  if (j + i + DGNN_FAST_U < nsteps) issue(j + i + DGNN_FAST_U, ring[i]);
+                  if (j + i + DGNN_PACK_U < nsteps) issue(j + i + DGNN_PACK_U, ring[i]);
                   consume(x, j + i);
                 }
-                j += DGNN_FAST_U;
+                j += DGNN_PACK_U;
 #pragma unroll
-                for (int i = 0; i < DGNN_FAST_U; ++i)
+                for (int i = 0; i < DGNN_PACK_U; ++i)
                   if (j + i < nsteps) consume(ring[i], j + i);
               } else {
                 for (; j < nsteps; ++j) {
@@ -540,6 +566,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         const size_t poff = act ? (size_t)phead * P.F + (size_t)pq : 0;
         const bool pleader = act && qq == 0;
         const size_t pgoff = (BMODE == BWD_GMM && P.grad_sum) ? (size_t)pq : poff;
+        float4 ring[DGNN_PACK_U];
         auto issue = [&](int j, float4 &x) {
           const unsigned it = (unsigned)uniform_i32((int)stream[j]);
           const bool isu = (it & DGNN_BWD_UFLAG) != 0u;
@@ -551,7 +578,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         auto consume = [&](const float4 &x, int j) {
           const unsigned it = (unsigned)uniform_i32((int)stream[j]);
           if (it & DGNN_BWD_UFLAG) {
-            u = slot4_mask(x, pdup);
+            u = (P.F & 3) ? slot4_mask(x, pdup) : x;      // (wave-uniform: aligned widths skip the mask)
             ++k;
             return;
           }
@@ -610,29 +637,29 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           }
         };
         int j = 0;
-        if (nsteps >= 2 * DGNN_FAST_U) {
+        if (nsteps >= 2 * DGNN_PACK_U) {
 #pragma unroll
-          for (int i = 0; i < DGNN_FAST_U; ++i) {
+          for (int i = 0; i < DGNN_PACK_U; ++i) {
             issue(i, ring[i]);
             __builtin_amdgcn_sched_barrier(0);
           }
-          for (; j + 2 * DGNN_FAST_U <= nsteps; j += DGNN_FAST_U) {
+          for (; j + 2 * DGNN_PACK_U <= nsteps; j += DGNN_PACK_U) {
 #pragma unroll
-            for (int i = 0; i < DGNN_FAST_U; ++i) {
+            for (int i = 0; i < DGNN_PACK_U; ++i) {
               consume(ring[i], j + i);
-              issue(j + i + DGNN_FAST_U, ring[i]);
+              issue(j + i + DGNN_PACK_U, ring[i]);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
 #pragma unroll
-          for (int i = 0; i < DGNN_FAST_U; ++i) {
+          for (int i = 0; i < DGNN_PACK_U; ++i) {
             const float4 x = ring[i];
-            if (j + i + DGNN_FAST_U < nsteps) issue(j + i + DGNN_FAST_U, ring[i]);
+            if (j + i + DGNN_PACK_U < nsteps) issue(j + i + DGNN_PACK_U, ring[i]);
             consume(x, j + i);
           }
-          j += DGNN_FAST_U;
+          j += DGNN_PACK_U;
 #pragma unroll
-          for (int i = 0; i < DGNN_FAST_U; ++i)
+          for (int i = 0; i < DGNN_PACK_U; ++i)
             if (j + i < nsteps) consume(ring[i], j + i);
         } else {
           for (; j < nsteps; ++j) {
@@ -642,19 +669,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
           }
         }
         };   // run_packed
-        const int want_s = HC * P.fv > 4 ? HC * P.fv : 4;
-        const bool spec = P.pack_s == want_s && P.fv_const != 0;
-        bool ran = ran_hreg;
-        if (spec) {
-          if constexpr (HC * 16 <= 16) { if (!ran && P.fv == 16) { run_packed(std::integral_constant<int, 16>{}); ran = true; } }
-          if constexpr (HC * 8 <= 16)  { if (!ran && P.fv == 8)  { run_packed(std::integral_constant<int, 8>{});  ran = true; } }
-          if constexpr (HC * 4 <= 16)  { if (!ran && P.fv == 4)  { run_packed(std::integral_constant<int, 4>{});  ran = true; } }
-          if constexpr (HC * 2 <= 16)  { if (!ran && P.fv == 2)  { run_packed(std::integral_constant<int, 2>{});  ran = true; } }
+        if constexpr (PK >= 2) {
+          run_packed(std::integral_constant<int, PK>{});
+        } else {
+          if (!ran_hreg) run_packed(std::integral_constant<int, 0>{});
         }
-        if (!ran) run_packed(std::integral_constant<int, 0>{});
       }
     }
-    if constexpr (STEADY) {
+    if constexpr (STEADY && PK == 0) {
       if (!took_steady && P.steady && items >= 2 * DGNN_FAST_U) {
         took_steady = true;
         // one item of the stream, its row already in x
@@ -727,6 +749,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
         }
       }
     }
+    if constexpr (PK == 0) {
     if (!took_steady) {
   #pragma unroll
     for (int i = 0; i < DGNN_FAST_U; ++i) {
@@ -784,8 +807,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
       }
     }
     }
+    }
   }
   wave_lds_sync();
+  DGNN_PHASE_MARK(1, 3);
 
   // ---------------------------------------------------------------- d_i to CSR order
   if (P.dE == nullptr) return;      // grad_attn_row came out of the row pass (out_neg / a_neg given)

@@ -7,6 +7,8 @@
 
 namespace dgnn {
 
+// (non-template kernels: each is compiled by the one translation unit that launches it)
+#ifdef DGNN_TU_FORWARD
 // Forward.  Semantics of fused_forward_kernel (fused_gatconv_kernel.cu:24-118): row max of
 // LeakyReLU(attn_row[r,h]+attn_col[c,h]) from -1e38, sum of exp(e-max), then
 // out[r,h,:] = sum_j [mask_j > p] * exp(e_j-max)/sum / (1.0-p) * in_feat[c_j,h,:].
@@ -61,6 +63,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_fwd_row(
   }
 }
 
+#endif
+#ifdef DGNN_TU_BACKWARD
 // S[r,h] = <grad[r,h,:], out[r,h,:]>.  Equals the row term sum_j a_j g_j that
 // fused_backward_kernel builds in its first sweep (fused_gatconv_kernel.cu:906-931), because
 // out[r,h,:] = sum_j a_j*mask_j/(1-p) * in_feat[c_j,h,:] and g_j = mask_j/(1-p) * <grad[r],in_feat[c_j]>.
@@ -400,6 +404,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_gat_row_sum_long(int H, const in
   }
 }
 
+#endif
+#ifdef DGNN_TU_FORWARD
 // --------------------------------------------------------------------------- SpMM / GMM
 // One wave per CSR row.  WEIGHT = 0: caller-supplied edge values (GE-SpMM, phase 3 of
 // fused_gatconv_kernel.cu:87-117).  WEIGHT = 1: Gaussian kernel weight computed on the fly
@@ -446,4 +452,5 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_spmm_row(
 }
 
 
+#endif
 }  // namespace dgnn

@@ -31,6 +31,9 @@ namespace dgnn {
 #ifndef DGNN_FAST_U
 #define DGNN_FAST_U 3          // feature-row gathers in flight per wave (swept on MI355X: 1..16)
 #endif
+#ifndef DGNN_PACK_U
+#define DGNN_PACK_U 3          // load steps in flight per wave in the PACKED streams (narrow rows, both gather kernels)
+#endif
 #ifndef DGNN_FWD_ROWCACHE
 #define DGNN_FWD_ROWCACHE 1
 #endif
@@ -122,6 +125,7 @@ static inline int fast_pack_lanes(int rowv, bool vec4) {
 }
 #define DGNN_PACK_END 0x4000u      // step list entry: last step of its row segment
 
+#ifdef DGNN_TU_FORWARD   // non-template kernel: compiled by the forward translation unit only (gather.hip)
 // Row bookkeeping: empty rows are finished here (out = 0, edge_max = -1e38, edge_sum = 0:
 // fused_gatconv_kernel.cu:45,66,90) and every group learns the row its first edge belongs to.
 __global__ void k_fast_prep_rows(GatherParams P) {
@@ -146,6 +150,7 @@ __global__ void k_fast_prep_rows(GatherParams P) {
     }
   }
 }
+#endif
 
 template <int VEC>
 struct VecT;
@@ -270,9 +275,18 @@ __device__ __forceinline__ void store_row_summed(const GatherParams &P, int row,
 // keep the kernel without it (the extra path costs the 4 x 64 kernel 10 % through registers).
 // NEG (GAT only, float4 rows): also produce out_neg / a_neg (GatherParams); the weight staged in LDS
 // carries the sign bit of its score (weights are >= 0, so the bit is free).
-template <int MODE, int VEC, int NS, int HT, bool STEADY, bool NEG = false>
+// PS (STEADY only) = lanes per row of the PACKED phase C as a compile-time constant (4, 8 or 16: rows
+// of at most that many float4 slots), 0 = the one-edge-per-step streams.  The host launches PS ==
+// P.pack_s; a kernel then carries ONE form of phase C instead of all of them (registers and code
+// of the others cost the narrow kernels occupancy, see k_bwd_col_gather's PK).
+template <int MODE, int VEC, int NS, int HT, bool STEADY, bool NEG = false, int PS = 0>
 __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) {
+  static_assert(PS == 0 || (STEADY && NS == 1 && VEC == 4), "the packed phase C exists in the narrow float4 instantiations only");
   constexpr int HTA = HT > 0 ? HT : 1;     // array extent that is legal for HT == 0 too
+#ifndef DGNN_FWD_HTB
+#define DGNN_FWD_HTB 2                     // probe builds: 8 x 8 forward 110 VGPRs at once, 86 in fours, 71 in twos
+#endif
+  constexpr int HTB = HTA > DGNN_FWD_HTB ? DGNN_FWD_HTB : HTA;   // heads per block of the softmax phase
   using V = VecT<VEC>;
   using vec_t = typename V::type;
   extern __shared__ __align__(16) float lds_raw[];
@@ -280,9 +294,10 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   const int lane = lane_id();
   const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
   if (t >= P.T) return;
+  DGNN_PHASE_DECL();
   if (MODE == MODE_GAT) drop_resolve(P.rng);
   const int L = P.L, H = P.H;
-  const bool packed = STEADY && P.pack_s > 0;
+  constexpr bool packed = PS != 0;        // the host launches PS == P.pack_s
   float *sc = lds_raw + (size_t)wib * fast_wave_lds_floats(H, L, packed);   // [L][H] score terms -> weights
   unsigned *cidx = (unsigned *)(sc + (size_t)L * H);      // [L] column id | ROWEND
   int *dq = (int *)(cidx + L);                            // [L] flush destinations, in row order
@@ -294,6 +309,22 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   const int e0 = t * L;
   const int e1 = min(e0 + L, P.nnz);
   const int cnt = e1 - e0;
+
+  // The group's first row, its start and the row cache of phase B are fetched HERE: three dependent
+  // memory latencies (task_row0 -> row_ptr -> the cache line of row ends) that would otherwise
+  // start after phase A's waits now run under them.
+  const int r_first = uniform_i32(P.task_row0[t]);
+  const int rs_first = uniform_i32(P.row_ptr[r_first]);
+#if DGNN_FWD_ROWCACHE
+  constexpr bool ARC = MODE == MODE_GAT && HT > 0 && HT <= 4;    // attn_row of the cached rows in registers too
+  int rp_first = P.row_ptr[min(r_first + 1 + lane, P.m)];
+  float4 ar_first = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == MODE_GAT && HT == 0 && H == 4) ar_first = *(const float4 *)(P.attn_row + (size_t)min(r_first + lane, P.m - 1) * 4);
+  float arc[HTA];
+#pragma unroll
+  for (int h = 0; h < HTA; ++h) arc[h] = 0.f;
+  if constexpr (ARC) ld_heads<HTA>(arc, P.attn_row + (size_t)min(r_first + lane, P.m - 1) * HTA);
+#endif
 
   // ---------------------------------------------------------------- phase A: stage
   for (int p = lane; p < cnt; p += DGNN_WAVE) {
@@ -318,6 +349,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     }
   }
   wave_lds_sync();
+  DGNN_PHASE_MARK(0, 0);
 
   // ---------------------------------------------------------------- phase B: rows of the group
   // a_neg: without dropout the staged weight is the softmax weight itself and phase C sums it
@@ -327,16 +359,15 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   const bool batch4 = P.batch_rows != 0;
   int nflush = 0;
   {
-    int r = uniform_i32(P.task_row0[t]);
-    int rs = uniform_i32(P.row_ptr[r]);
+    int r = r_first;
+    int rs = rs_first;
 #if DGNN_FWD_ROWCACHE
     // Row ends (and, for four heads, the rows' own score terms) of 64 consecutive rows are
     // fetched with ONE coalesced load per lane and handed out by v_readlane: a group of short
     // rows no longer pays two dependent memory latencies per row.
     int rbase = r;
-    int rp_c = P.row_ptr[min(rbase + 1 + lane, P.m)];
-    float4 ar_c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == MODE_GAT && HT == 0 && H == 4) ar_c = *(const float4 *)(P.attn_row + (size_t)min(rbase + lane, P.m - 1) * 4);
+    int rp_c = rp_first;
+    float4 ar_c = ar_first;
 #endif
     while (true) {
 #if DGNN_FWD_ROWCACHE
@@ -344,6 +375,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         rbase = r;
         rp_c = P.row_ptr[min(rbase + 1 + lane, P.m)];
         if (MODE == MODE_GAT && HT == 0 && H == 4) ar_c = *(const float4 *)(P.attn_row + (size_t)min(rbase + lane, P.m - 1) * 4);
+        if constexpr (ARC) ld_heads<HTA>(arc, P.attn_row + (size_t)min(rbase + lane, P.m - 1) * HTA);
       }
       const int rk = r - rbase;
       const int re = bcast_i32(rp_c, rk);
@@ -377,69 +409,79 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           const int p = rstart - e0 + li;
           const bool live = mine && (e0 + p) < rend;
           const int rq = r + (mine ? qd : 0);
-          float arow[HTA], e[HTA], mx[HTA], pe[HTA], sm[HTA];
-          ld_heads<HTA>(arow, P.attn_row + (size_t)rq * HTA);
+          // heads in blocks of at most four: eight heads at once kept ~64 values per lane alive (arow, e,
+          // mx, pe, sm, an, w, mask) and the 8 x 8 kernel at 110 VGPRs = four waves per SIMD
 #pragma unroll
-          for (int h = 0; h < HTA; ++h) e[h] = DGNN_NEG_INIT;
-          if (live) {
-            float c[HTA];
-            ld_heads<HTA>(c, sc + (size_t)p * HTA);
+          for (int h0 = 0; h0 < HTA; h0 += HTB) {
+            float arow[HTB], e[HTB], mx[HTB], pe[HTB], sm[HTB];
+            if constexpr (ARC) {      // row rq's terms sit in lane rk + qd of the row cache: a cross-lane read, no memory latency
 #pragma unroll
-            for (int h = 0; h < HTA; ++h) e[h] = leaky_relu(arow[h] + c[h], P.slope);
-          }
-#pragma unroll
-          for (int h = 0; h < HTA; ++h) mx[h] = row16_reduce(e[h], OpMax());
-#pragma unroll
-          for (int h = 0; h < HTA; ++h) pe[h] = live ? expf(e[h] - mx[h]) : 0.f;
-#pragma unroll
-          for (int h = 0; h < HTA; ++h) sm[h] = row16_reduce(pe[h], OpSum());
-          float an[HTA];
-          if constexpr (NEG) {
-            if (an_in_b) {
-#pragma unroll
-              for (int h = 0; h < HTA; ++h)
-                an[h] = row16_reduce((live && e[h] < 0.f) ? pe[h] : 0.f, OpSum()) / sm[h];
+              for (int h = 0; h < HTB; ++h) arow[h] = __shfl(arc[h0 + h], rk + (mine ? qd : 0), DGNN_WAVE);
+            } else {
+              ld_heads<HTB>(arow, P.attn_row + (size_t)rq * HTA + h0);
             }
-          }
-          if (live) {
-            float w[HTA];
 #pragma unroll
-            for (int h = 0; h < HTA; ++h) w[h] = pe[h] / sm[h];                                // :102
-            if (P.edge_mask != nullptr || P.rng.on) {
-              float mk[HTA];
-              if (P.rng.on) {
+            for (int h = 0; h < HTB; ++h) e[h] = DGNN_NEG_INIT;
+            if (live) {
+              float c[HTB];
+              ld_heads<HTB>(c, sc + (size_t)p * HTA + h0);
 #pragma unroll
-                for (int h = 0; h < HTA; ++h) mk[h] = drop_uniform(P.rng, (unsigned long long)(e0 + p) * HTA + h);
-              } else {
-                ld_heads<HTA>(mk, P.edge_mask + (size_t)(e0 + p) * HTA);
-              }
+              for (int h = 0; h < HTB; ++h) e[h] = leaky_relu(arow[h] + c[h], P.slope);
+            }
 #pragma unroll
-              for (int h = 0; h < HTA; ++h) {
-                if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
-                w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
+            for (int h = 0; h < HTB; ++h) mx[h] = row16_reduce(e[h], OpMax());
+#pragma unroll
+            for (int h = 0; h < HTB; ++h) pe[h] = live ? exp_nonpos(e[h] - mx[h]) : 0.f;
+#pragma unroll
+            for (int h = 0; h < HTB; ++h) sm[h] = row16_reduce(pe[h], OpSum());
+            float an[HTB];
+            if constexpr (NEG) {
+              if (an_in_b) {
+#pragma unroll
+                for (int h = 0; h < HTB; ++h)
+                  an[h] = div_pos(row16_reduce((live && e[h] < 0.f) ? pe[h] : 0.f, OpSum()), sm[h]);
               }
             }
-            if constexpr (NEG) {
+            if (live) {
+              float w[HTB];
 #pragma unroll
-              for (int h = 0; h < HTA; ++h)
-                if (e[h] < 0.f) w[h] = -w[h];
+              for (int h = 0; h < HTB; ++h) w[h] = div_pos(pe[h], sm[h]);                        // :102
+              if (P.edge_mask != nullptr || P.rng.on) {
+                float mk[HTB];
+                if (P.rng.on) {
+#pragma unroll
+                  for (int h = 0; h < HTB; ++h) mk[h] = drop_uniform(P.rng, (unsigned long long)(e0 + p) * HTA + h0 + h);
+                } else {
+                  ld_heads<HTB>(mk, P.edge_mask + (size_t)(e0 + p) * HTA + h0);
+                }
+#pragma unroll
+                for (int h = 0; h < HTB; ++h) {
+                  if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
+                  w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
+                }
+              }
+              if constexpr (NEG) {
+#pragma unroll
+                for (int h = 0; h < HTB; ++h)
+                  if (e[h] < 0.f) w[h] = -w[h];
+              }
+              st_heads<HTB>(sc + (size_t)p * HTA + h0, w);
             }
-            st_heads<HTA>(sc + (size_t)p * HTA, w);
-            if (e0 + p == rend - 1) cidx[p] |= DGNN_ROWEND;
+            if (mine && li == 0) {
+              if (P.edge_max != nullptr) {
+                st_heads<HTB>(P.edge_max + (size_t)rq * HTA + h0, mx);
+                st_heads<HTB>(P.edge_sum + (size_t)rq * HTA + h0, sm);
+              }
+              if constexpr (NEG) {
+                if (an_in_b) st_heads<HTB>(P.a_neg + (size_t)rq * HTA + h0, an);
+              }
+            }
           }
-          if (mine && li == 0) {
-            if (P.edge_max != nullptr) {
-              st_heads<HTA>(P.edge_max + (size_t)rq * HTA, mx);
-              st_heads<HTA>(P.edge_sum + (size_t)rq * HTA, sm);
-            }
-            if constexpr (NEG) {
-              if (an_in_b) st_heads<HTA>(P.a_neg + (size_t)rq * HTA, an);
-            }
-            dq[nflush + qd] = rq;
-          }
+          if (live && e0 + p == rend - 1) cidx[p] |= DGNN_ROWEND;
+          if (mine && li == 0) dq[nflush + qd] = rq;
           if constexpr (STEADY) {
             if (packed) {
-              const int G = DGNN_WAVE / P.pack_s;
+              constexpr int G = DGNN_WAVE / (PS > 0 ? PS : DGNN_WAVE);
               int off = nsteps, myoff = nsteps, myns = 0;
               int prev = rs;
 #pragma unroll
@@ -477,71 +519,79 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           // the whole segment fits one wave pass: all HT heads at once (lane = edge)
           const int p = a + lane;
           const bool live = p < b;
-          float arow[HTA], e[HTA], mx[HTA], pe[HTA], sm[HTA];
-          ld_heads<HTA>(arow, P.attn_row + (size_t)r * HTA);
 #pragma unroll
-          for (int h = 0; h < HTA; ++h) e[h] = DGNN_NEG_INIT;
-          if (live) {
-            float c[HTA];
-            ld_heads<HTA>(c, sc + (size_t)p * HTA);
+          for (int h0 = 0; h0 < HTA; h0 += HTB) {       // heads in blocks of at most four (registers, see above)
+            float arow[HTB], e[HTB], mx[HTB], pe[HTB], sm[HTB];
+            if constexpr (ARC) {
 #pragma unroll
-            for (int h = 0; h < HTA; ++h) e[h] = leaky_relu(arow[h] + c[h], P.slope);
-          }
-#pragma unroll
-          for (int h = 0; h < HTA; ++h) mx[h] = wave_max(e[h]);
-#pragma unroll
-          for (int h = 0; h < HTA; ++h) pe[h] = live ? expf(e[h] - mx[h]) : 0.f;
-#pragma unroll
-          for (int h = 0; h < HTA; ++h) sm[h] = wave_sum(pe[h]);
-          float an[HTA];
-          if constexpr (NEG) {
-            if (an_in_b) {
-#pragma unroll
-              for (int h = 0; h < HTA; ++h) {
-                an[h] = wave_sum((live && e[h] < 0.f) ? pe[h] : 0.f);
-                if (whole) an[h] = an[h] / sm[h];
-              }
-            }
-          }
-          if (live) {
-            float w[HTA];
-#pragma unroll
-            for (int h = 0; h < HTA; ++h) w[h] = whole ? pe[h] / sm[h] : pe[h];              // :102
-            if (P.edge_mask != nullptr || P.rng.on) {
-              float mk[HTA];
-              if (P.rng.on) {
-#pragma unroll
-                for (int h = 0; h < HTA; ++h) mk[h] = drop_uniform(P.rng, (unsigned long long)(e0 + p) * HTA + h);
-              } else {
-                ld_heads<HTA>(mk, P.edge_mask + (size_t)(e0 + p) * HTA);
-              }
-#pragma unroll
-              for (int h = 0; h < HTA; ++h) {
-                if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
-                w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
-              }
-            }
-            if constexpr (NEG) {
-#pragma unroll
-              for (int h = 0; h < HTA; ++h)
-                if (e[h] < 0.f) w[h] = -w[h];
-            }
-            st_heads<HTA>(sc + (size_t)p * HTA, w);
-          }
-          if (lane == 0) {
-            if (whole) {
-              if (P.edge_max != nullptr) {
-                st_heads<HTA>(P.edge_max + (size_t)r * HTA, mx);
-                st_heads<HTA>(P.edge_sum + (size_t)r * HTA, sm);
-              }
-              if constexpr (NEG) {
-                if (an_in_b) st_heads<HTA>(P.a_neg + (size_t)r * HTA, an);
-              }
+              for (int h = 0; h < HTB; ++h) arow[h] = bcast_f32(arc[h0 + h], rk);
             } else {
-              st_heads<HTA>(slot_ptr + P.HF, mx);
-              st_heads<HTA>(slot_ptr + P.HF + HTA, sm);
+              ld_heads<HTB>(arow, P.attn_row + (size_t)r * HTA + h0);
+            }
+#pragma unroll
+            for (int h = 0; h < HTB; ++h) e[h] = DGNN_NEG_INIT;
+            if (live) {
+              float c[HTB];
+              ld_heads<HTB>(c, sc + (size_t)p * HTA + h0);
+#pragma unroll
+              for (int h = 0; h < HTB; ++h) e[h] = leaky_relu(arow[h] + c[h], P.slope);
+            }
+#pragma unroll
+            for (int h = 0; h < HTB; ++h) mx[h] = wave_max(e[h]);
+#pragma unroll
+            for (int h = 0; h < HTB; ++h) pe[h] = live ? exp_nonpos(e[h] - mx[h]) : 0.f;
+#pragma unroll
+            for (int h = 0; h < HTB; ++h) sm[h] = wave_sum(pe[h]);
+            float an[HTB];
+            if constexpr (NEG) {
+              if (an_in_b) {
+#pragma unroll
+                for (int h = 0; h < HTB; ++h) {
+                  an[h] = wave_sum((live && e[h] < 0.f) ? pe[h] : 0.f);
+                  if (whole) an[h] = div_pos(an[h], sm[h]);
+                }
+              }
+            }
+            if (live) {
+              float w[HTB];
+#pragma unroll
+              for (int h = 0; h < HTB; ++h) w[h] = whole ? div_pos(pe[h], sm[h]) : pe[h];      // :102
+              if (P.edge_mask != nullptr || P.rng.on) {
+                float mk[HTB];
+                if (P.rng.on) {
+#pragma unroll
+                  for (int h = 0; h < HTB; ++h) mk[h] = drop_uniform(P.rng, (unsigned long long)(e0 + p) * HTA + h0 + h);
+                } else {
+                  ld_heads<HTB>(mk, P.edge_mask + (size_t)(e0 + p) * HTA + h0);
+                }
+#pragma unroll
+                for (int h = 0; h < HTB; ++h) {
+                  if (!(mk[h] > P.attn_drop)) w[h] = 0.f;                                      // :95
+                  w[h] = drop_scale(w[h], P.attn_drop);                                        // :104
+                }
+              }
               if constexpr (NEG) {
-                if (an_in_b) st_heads<HTA>(slot_ptr + P.HF + 2 * HTA, an);
+#pragma unroll
+                for (int h = 0; h < HTB; ++h)
+                  if (e[h] < 0.f) w[h] = -w[h];
+              }
+              st_heads<HTB>(sc + (size_t)p * HTA + h0, w);
+            }
+            if (lane == 0) {
+              if (whole) {
+                if (P.edge_max != nullptr) {
+                  st_heads<HTB>(P.edge_max + (size_t)r * HTA + h0, mx);
+                  st_heads<HTB>(P.edge_sum + (size_t)r * HTA + h0, sm);
+                }
+                if constexpr (NEG) {
+                  if (an_in_b) st_heads<HTB>(P.a_neg + (size_t)r * HTA + h0, an);
+                }
+              } else {
+                st_heads<HTB>(slot_ptr + P.HF + h0, mx);
+                st_heads<HTB>(slot_ptr + P.HF + HTA + h0, sm);
+                if constexpr (NEG) {
+                  if (an_in_b) st_heads<HTB>(slot_ptr + P.HF + 2 * HTA + h0, an);
+                }
               }
             }
           }
@@ -567,8 +617,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           mx.x = wave_max(e4.x); mx.y = wave_max(e4.y); mx.z = wave_max(e4.z); mx.w = wave_max(e4.w);
           float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
           if (live) {
-            pe.x = expf(e4.x - mx.x); pe.y = expf(e4.y - mx.y);
-            pe.z = expf(e4.z - mx.z); pe.w = expf(e4.w - mx.w);
+            pe.x = exp_nonpos(e4.x - mx.x); pe.y = exp_nonpos(e4.y - mx.y);
+            pe.z = exp_nonpos(e4.z - mx.z); pe.w = exp_nonpos(e4.w - mx.w);
           }
           float4 sm;
           sm.x = wave_sum(pe.x); sm.y = wave_sum(pe.y); sm.z = wave_sum(pe.z); sm.w = wave_sum(pe.w);
@@ -577,12 +627,12 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             if (an_in_b) {
               an4.x = wave_sum(e4.x < 0.f ? pe.x : 0.f); an4.y = wave_sum(e4.y < 0.f ? pe.y : 0.f);
               an4.z = wave_sum(e4.z < 0.f ? pe.z : 0.f); an4.w = wave_sum(e4.w < 0.f ? pe.w : 0.f);
-              if (whole) { an4.x /= sm.x; an4.y /= sm.y; an4.z /= sm.z; an4.w /= sm.w; }
+              if (whole) { an4.x = div_pos(an4.x, sm.x); an4.y = div_pos(an4.y, sm.y); an4.z = div_pos(an4.z, sm.z); an4.w = div_pos(an4.w, sm.w); }
             }
           }
           if (live) {
             float4 w4 = pe;
-            if (whole) { w4.x /= sm.x; w4.y /= sm.y; w4.z /= sm.z; w4.w /= sm.w; }   // :102
+            if (whole) { w4.x = div_pos(w4.x, sm.x); w4.y = div_pos(w4.y, sm.y); w4.z = div_pos(w4.z, sm.z); w4.w = div_pos(w4.w, sm.w); }   // :102
             if (P.edge_mask != nullptr || P.rng.on) {
               const float4 mk = P.rng.on ? drop_uniform4(P.rng, (unsigned long long)(e0 + p))
                                          : *(const float4 *)(P.edge_mask + (size_t)(e0 + p) * 4);
@@ -628,7 +678,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             float sm = 0.f, an = 0.f;
             for (int p = a + lane; p < b; p += DGNN_WAVE) {
               const float ev = leaky_relu(arh + sc[(size_t)p * H + h], P.slope);
-              const float pe = expf(ev - mx);
+              const float pe = exp_nonpos(ev - mx);
               sc[(size_t)p * H + h] = (NEG && ev < 0.f) ? -pe : pe;      // NEG: sign bit = (score < 0)
               sm += pe;
               if (NEG && ev < 0.f) an += pe;
@@ -637,14 +687,14 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             if constexpr (NEG) {
               if (an_in_b) {
                 an = wave_sum(an);
-                if (whole) an = an / sm;
+                if (whole) an = div_pos(an, sm);
               }
             }
             for (int p = a + lane; p < b; p += DGNN_WAVE) {
               float w = sc[(size_t)p * H + h];
               const bool ng = NEG && (__float_as_uint(w) & 0x80000000u) != 0u;
               if constexpr (NEG) w = fabsf(w);
-              if (whole) w = w / sm;                       // exp(e-max)/sum per edge, :102
+              if (whole) w = div_pos(w, sm);               // exp(e-max)/sum per edge, :102
               if (P.edge_mask != nullptr || P.rng.on) {
                 const float mk = P.rng.on ? drop_uniform(P.rng, (unsigned long long)(e0 + p) * H + h)
                                           : P.edge_mask[(size_t)(e0 + p) * H + h];
@@ -679,7 +729,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         ++nflush;
         if constexpr (STEADY) {
           if (packed) {
-            const int G = DGNN_WAVE / P.pack_s;
+            constexpr int G = DGNN_WAVE / (PS > 0 ? PS : DGNN_WAVE);
             const int ns = (b - a + G - 1) / G;
             for (int j = lane; j < ns; j += DGNN_WAVE) {
               const int p0 = a + j * G;
@@ -696,6 +746,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
     }
   }
   wave_lds_sync();
+  DGNN_PHASE_MARK(0, 1);
 
   // ---------------------------------------------------------------- phase C, packed (narrow rows)
   // A row of S <= 32 float4 slots leaves 64 - S lanes of a one-edge-per-step walk idle and the
@@ -705,9 +756,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
   // and at the row's last step the G partials are added across groups (xor shuffles) and stored.
   // Steps never span rows (the step list is built in phase B), so no lane ever mixes rows; idle
   // groups of a row's last step re-read the step's first edge with weight 0.
-  if constexpr (STEADY && NS == 1 && VEC == 4) {
-    if (packed) {
-      const int S = P.pack_s;
+  if constexpr (PS != 0) {
+    {
+      constexpr int S = PS;
       const int g = lane / S, sl = lane % S;
       const bool active = sl < P.rowv;
       int head;
@@ -718,8 +769,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accn = acc;
       float an = 0.f;
       const bool an_leader = active && g == 0 && first_of_head;
-      float4 ring[DGNN_FAST_U];
-      float wring[DGNN_FAST_U];
+      float4 ring[DGNN_PACK_U];
+      float wring[DGNN_PACK_U];
       int q = 0;
       auto issue = [&](int j, float4 &x, float &w) {
         const unsigned it = (unsigned)uniform_i32((int)steps[j]);
@@ -733,6 +784,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       auto consume = [&](const float4 &x, float w, int j) {
         acc_edge<NEG, 4>(acc, accn, an, w, x);
         if (uniform_i32((int)steps[j]) & (int)DGNN_PACK_END) {
+#pragma unroll
           for (int off = S; off < DGNN_WAVE; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off, DGNN_WAVE);
             acc.y += __shfl_xor(acc.y, off, DGNN_WAVE);
@@ -769,31 +821,31 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
         }
       };
       int j = 0;
-      if (nsteps >= 2 * DGNN_FAST_U) {
+      if (nsteps >= 2 * DGNN_PACK_U) {
 #pragma unroll
-        for (int k = 0; k < DGNN_FAST_U; ++k) {
+        for (int k = 0; k < DGNN_PACK_U; ++k) {
           issue(k, ring[k], wring[k]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        for (; j + 2 * DGNN_FAST_U <= nsteps; j += DGNN_FAST_U) {
+        for (; j + 2 * DGNN_PACK_U <= nsteps; j += DGNN_PACK_U) {
 #pragma unroll
-          for (int k = 0; k < DGNN_FAST_U; ++k) {
+          for (int k = 0; k < DGNN_PACK_U; ++k) {
             consume(ring[k], wring[k], j + k);
-            issue(j + k + DGNN_FAST_U, ring[k], wring[k]);
+            issue(j + k + DGNN_PACK_U, ring[k], wring[k]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         // the ring holds steps j .. j+U-1; at most U-1 further steps remain
 #pragma unroll
-        for (int k = 0; k < DGNN_FAST_U; ++k) {
+        for (int k = 0; k < DGNN_PACK_U; ++k) {
           const float4 x = ring[k];
           const float w = wring[k];
-          if (j + k + DGNN_FAST_U < nsteps) issue(j + k + DGNN_FAST_U, ring[k], wring[k]);
+          if (j + k + DGNN_PACK_U < nsteps) issue(j + k + DGNN_PACK_U, ring[k], wring[k]);
           consume(x, w, j + k);
         }
-        j += DGNN_FAST_U;
+        j += DGNN_PACK_U;
 #pragma unroll
-        for (int k = 0; k < DGNN_FAST_U; ++k)
+        for (int k = 0; k < DGNN_PACK_U; ++k)
           if (j + k < nsteps) consume(ring[k], wring[k], j + k);
       } else {
         for (; j < nsteps; ++j) {
@@ -803,6 +855,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
           consume(x, w, j);
         }
       }
+      DGNN_PHASE_MARK(0, 2);
       return;
     }
   }
@@ -1030,6 +1083,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
       }
     }
   }
+  DGNN_PHASE_MARK(0, 3);
 }
 
 // Merge the partial slots of rows cut by a group boundary.  One wave per boundary t (1..T-1);

@@ -1,0 +1,94 @@
+// Host-side helpers shared by the translation units of the row-gather family (gather.hip: forward
+// side; gather_bwd.hip: backward side): alignment tests, the optional kernel timer, the forward's
+// workspace layout and the forward launcher the backward calls when it has to rebuild out_feat.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+
+#include "gather_fast.hpp"
+
+namespace dgnn {
+namespace host {
+
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// DGNN_FORCE_GENERIC=1 routes everything through the wave-per-row kernels (A/B testing).
+inline bool force_generic() {
+  const char *e = std::getenv("DGNN_FORCE_GENERIC");
+  return e != nullptr && e[0] == '1';
+}
+
+// Optional timing of the two dominant kernels (DGNN_TIMING=1): HIP events recorded on the launch
+// stream right around the kernel, read back with dgnn_debug_last_kernel_ms().  Off by default;
+// this is the only process-global state in the library and it never changes results.
+struct KernelTimer {
+  bool on = false, init = false;
+  hipEvent_t ev[2][2];
+  bool valid[2] = {false, false};
+  char name[2][96] = {{0}, {0}};   // template instantiation of the kernel last timed, as rocprofv3 prints it
+};
+extern KernelTimer g_timer;      // defined in gather.hip
+inline bool timing_on() {
+  if (!g_timer.init) {
+    g_timer.init = true;
+    g_timer.on = env_int("DGNN_TIMING", 0) != 0;
+    if (g_timer.on)
+      for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 2; ++i)
+          if (hipEventCreate(&g_timer.ev[k][i]) != hipSuccess) g_timer.on = false;
+  }
+  return g_timer.on;
+}
+inline void timer_mark(int which, int edge, hipStream_t st) {
+  if (timing_on()) {
+    (void)hipEventRecord(g_timer.ev[which][edge], st);
+    if (edge == 1) g_timer.valid[which] = true;
+  }
+}
+
+// ----------------------------------------------------------------------------- forward side
+struct FwdLayout {
+  int L, T, slot_stride, slot_neg;
+  size_t off_rows, off_slots, total;
+};
+
+// neg: partial slots also hold the negative-score aggregate and weight sum (GatherParams::out_neg)
+inline FwdLayout fwd_layout(int nnz, int h, int f, bool neg = false) {
+  FwdLayout w;
+  w.L = fast_group_size(h, nnz, narrow_rows(h, f));
+  w.T = (nnz + w.L - 1) / w.L;
+  w.slot_neg = (int)align_up((size_t)h * f + 3 * (size_t)h, 4);
+  w.slot_stride = neg ? (int)align_up((size_t)w.slot_neg + (size_t)h * f, 4)
+                      : (int)align_up((size_t)h * f + 2 * (size_t)h, 4);
+  size_t o = 0;
+  w.off_rows = o;
+  o += align_up(sizeof(int) * (size_t)(w.T > 0 ? w.T : 1), 256);
+  w.off_slots = o;
+  o += align_up(sizeof(float) * 2 * (size_t)w.T * w.slot_stride, 256);
+  w.total = o;
+  return w;
+}
+
+inline bool fwd_fast_ok(int m, int h) { return h <= DGNN_FAST_HMAX && m < (1 << 30) && !force_generic(); }
+
+inline int check_dims(int m, int nnz, int h, int f) {
+  if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return DGNN_ERR_BAD_ARG;
+  if ((long long)h * f > (1 << 20)) return DGNN_ERR_UNSUPPORTED;
+  return DGNN_OK;
+}
+
+
+// gather.hip: the fused GAT forward on the fast or the generic kernels (the backward uses it to
+// rebuild out_feat for callers with the reference signature)
+int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
+                   const float *attn_row, const float *attn_col, const int *row_ptr,
+                   const int *col_ind, const float *in_feat, const float *edge_mask,
+                   float *edge_max, float *edge_sum, float *out_feat, void *workspace,
+                   size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0, nullptr},
+                   float *out_neg = nullptr, float *a_neg = nullptr);
+
+}  // namespace host
+}  // namespace dgnn

@@ -116,10 +116,10 @@ def shapes(workload="products"):
         out, emax, esum, emask, on, an = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=True)
         if not neg:
             on = an = None
-        tf = timeit(lambda: fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=neg), iters=3, warm=1)
+        tf = timeit(lambda: fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=neg), iters=int(os.environ.get("DGNN_BENCH_ITERS", "3")), warm=1)
         tb = timeit(lambda: fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"],
                                             emax, esum, emask, x, ar, ac, go, out_feat=out, out_neg=on, a_neg=an),
-                    iters=3, warm=1)
+                    iters=int(os.environ.get("DGNN_BENCH_ITERS", "3")), warm=1)
         ab = bench.algorithmic_bytes(n, nnz, H, F, neg=neg and on is not None)
         print(json.dumps({"op": f"gat {workload}", "H": H, "F": F, "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
                           "fwd_GBps": round(ab["fwd"] / tf / 1e6, 1), "bwd_GBps": round(ab["bwd_csc"] / tb / 1e6, 1)}), flush=True)
@@ -168,7 +168,7 @@ def reddit():
                       "bwd_ms": round(tb, 3), "edges_per_s": round(nnz / (tf + tb) * 1e3),
                       "fwd_GBps": round(ab["fwd"] / tf / 1e6, 1), "bwd_GBps": round(ab["bwd_csc"] / tb / 1e6, 1)}), flush=True)
     ts = timeit(lambda: spmm.spmm_csr(g["row_ptr"], g["col_ind"], val, x), iters=5, warm=2)
-    td = timeit(lambda: mhsddmm.mhsddmm(g["row_ptr"], g["col_ind"], go, x), iters=3, warm=1)
+    td = timeit(lambda: mhsddmm.mhsddmm(g["row_ptr"], g["col_ind"], go, x), iters=int(os.environ.get("DGNN_BENCH_ITERS", "3")), warm=1)
     print(json.dumps({"op": "spmm_csr (Reddit-shaped)", "ms": round(ts, 3),
                       "GBps": round((nnz * (4 * H * F + 4 * H + 4) + n * 4 * H * F) / ts / 1e6, 1)}), flush=True)
     print(json.dumps({"op": "mhsddmm (Reddit-shaped)", "ms": round(td, 3),

@@ -18,8 +18,11 @@ n = g["n"]
 x = torch.rand((n, H, F), device=dev) - 0.4
 ar, ac = torch.rand((n, H), device=dev) - 0.6, torch.rand((n, H), device=dev) - 0.4
 go = torch.rand((n, H, F), device=dev) - 0.5
+neg = os.environ.get("DGNN_BENCH_NEG", "1") == "1"       # the operator's path: negative-score pair
 for _ in range(2):
-    out, emax, esum, emask = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0)
+    out, emax, esum, emask, on, an = fg.gat_forward(ar, ac, g["row_ptr"], g["col_ind"], 0.2, x, 0.0, neg=True)
+    if not neg:
+        on = an = None
     fg.gat_backward(0.2, 0.0, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"], g["permute"], emax, esum, emask,
-                    x, ar, ac, go, out_feat=out)
+                    x, ar, ac, go, out_feat=out, out_neg=on, a_neg=an)
 torch.cuda.synchronize()

@@ -26,4 +26,7 @@ fi
 if [ "${DGNN_PROFILE_SQ:-0}" = "1" ]; then
   timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $out/sq -- "${short[@]}" > $out/sq.log 2>&1 || exit 1
 fi
+if [ "${DGNN_PROFILE_SQ2:-0}" = "1" ]; then     # where the cycles go (a failing counter name must not end the script)
+  timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM --output-format csv -d $out/sq2 -- "${short[@]}" > $out/sq2.log 2>&1 || echo "sq2 pass failed (see sq2.log)"
+fi
 tail -1 $out/trace.log | cut -c1-700
