@@ -150,6 +150,46 @@ def measured_traffic(workload, kernel_name):
     return parts["FETCH_SIZE"] + parts["WRITE_SIZE"], os.path.relpath(src, ROOT)
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_signature_function():
+    """The reference's own autograd wrapper (dgNN/operators/fused_gatconv.py:12-34) restated on our
+    drop-in module: gat_forward with the reference's seven positional arguments, the SAME eleven saved
+    tensors (the fourth result included, handed back untouched), gat_backward with its fourteen.  What
+    INTEGRATION.md option A gives a user who keeps the reference's Python unmodified."""
+    from dgnn_amd.native import fused_gatconv as fused_gat
+
+    class FusedGATFunction(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope, in_feat, attn_drop):
+            out_feat, edge_max, edge_sum, edge_mask = fused_gat.gat_forward(attn_row, attn_col, row_ptr, col_ind,
+                                                                            negative_slope, in_feat, attn_drop)
+            ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat,
+                                  attn_row, attn_col)
+            ctx.negative_slope, ctx.attn_drop = negative_slope, attn_drop
+            return out_feat
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            (row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, in_feat, attn_row,
+             attn_col) = ctx.saved_tensors
+            grad_out = grad_out.contiguous()
+            grad_feat, grad_attn_row, grad_attn_col = fused_gat.gat_backward(
+                ctx.negative_slope, ctx.attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
+                edge_mask, in_feat, attn_row, attn_col, grad_out)
+            return grad_attn_row, grad_attn_col, None, None, None, None, None, None, grad_feat, None
+
+    return FusedGATFunction.apply
+
+
 def cpu_baseline(name, seed=0):
     """The oracle (float32 restatement of the reference kernels, OpenMP over rows) timed on the
     host cores on a bounded sample: an R-MAT graph of the same shape family at 1/8 scale (tens
@@ -163,6 +203,7 @@ def cpu_baseline(name, seed=0):
     g = rmat_graph(sc, ns, max(es - ns, 1), seed)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], H, F, seed)
     cores = min(oracle.max_threads(), 16)
+    torch_threads = torch.get_num_threads()          # (read before the oracle changes the OpenMP setting)
     oracle.set_threads(cores)
     t0 = time.perf_counter()
     out, emax, esum = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], SLOPE, in_feat, 0.0)
@@ -170,7 +211,8 @@ def cpu_baseline(name, seed=0):
                         emax, esum, None, in_feat, attn_row, attn_col, grad)
     dt = time.perf_counter() - t0
     oracle.set_threads(1)
-    return {"value": g["nnz"] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+    return {"value": g["nnz"] / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "cpu_count": os.cpu_count(), "torch_threads": torch_threads,
             "sample": f"oracle f32 fwd+bwd on a 1/{div} scale R-MAT of the same shape "
                       f"(n={g['n']}, nnz={g['nnz']}, {H}x{F}), {dt:.2f} s wall"}
 
@@ -278,6 +320,10 @@ def main():
                          "copies of the same size (everything but the wire; results are not meaningful)")
     ap.add_argument("--no-other-labels", action="store_true",
                     help="skip the extra steps on the other node labelling (profiling runs: one labelling per trace)")
+    ap.add_argument("--path", default="operator", choices=["operator", "reference-signature"],
+                    help="operator: dgnn_amd.operators.GATConvFuse (the default); reference-signature: the reference's "
+                         "own wrapper restated on the drop-in module (gat_forward / gat_backward with the reference's "
+                         "positional arguments only).  The single-GPU line reports the other path too")
     ap.add_argument("--dry", action="store_true", help="launcher check: gloo all-reduce on the CPU, no GPU work")
     args = ap.parse_args()
 
@@ -365,10 +411,13 @@ def main():
         ar = attn_row.requires_grad_()
         ac = attn_col.requires_grad_()
 
+        paths = {"operator": GATConvFuse, "reference-signature": reference_signature_function()}
+        fuse = paths[args.path]
+
         def step_fn():
             x.grad = ar.grad = ac.grad = None
-            out = GATConvFuse(ar, ac, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
-                              g["permute"], SLOPE, x, args.attn_drop)
+            out = fuse(ar, ac, g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"],
+                       g["permute"], SLOPE, x, args.attn_drop)
             out.backward(grad_out)
 
     def sync():
@@ -376,6 +425,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.reset_peak_memory_stats(device)     # graph construction is not part of a step
     for _ in range(args.warmup):
         step_fn()
     sync()
@@ -384,6 +434,9 @@ def main():
         step_fn()
     sync()
     dt = time.perf_counter() - t0
+    # peak device memory over the warm-up and timed steps, inputs and graph resident (the reference
+    # publishes peak memory per run: test/gat_result.csv)
+    peak_mem_mb = round(torch.cuda.max_memory_allocated(device) / 2**20)
     if use_pg:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -439,6 +492,7 @@ def main():
         del src, dst
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_from_profile": True,      # PMC bytes of the committed rocprofv3 run named above, not of this run
                 "kernel_instance": dom[3],
                 "device_copy_GBps": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4),
                 "kernel": dom[0], "algorithmic_bytes": dom[1], "kernel_ms": round(dom[2], 3),
@@ -485,7 +539,8 @@ def main():
                         if use_pg else None),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic", "peak_mem_MB": peak_mem_mb,
+            "host": {"cpu": cpu_model(), "torch_threads": torch.get_num_threads(), "cpu_count": os.cpu_count()},
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
                                    f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd, node labels {args.labels}"
                                    + (" (load-time relabelling, dgnn_amd.graph.relabel_nodes)" if args.labels == "scrambled" else ""),
@@ -499,6 +554,24 @@ def main():
             line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
                                  f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")
             line["value"] = runner.nnz_fwd / (ms_per_step * 1e-3)
+        if world == 1 and not use_pg and not args.force_dist and not args.simulate_rank:
+            # the same steps through the other calling convention (INTEGRATION.md option A / the operator)
+            line["config"]["path"] = args.path
+            other_path = "reference-signature" if args.path == "operator" else "operator"
+            fuse = paths[other_path]
+            for _ in range(2):
+                step_fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k_path = max(3, min(args.steps, 10))
+            for _ in range(k_path):
+                step_fn()
+            torch.cuda.synchronize()
+            ms_path = (time.perf_counter() - t0) / k_path * 1e3
+            line["other_path"] = {"path": other_path, "ms_per_step": round(ms_path, 3), "steps": k_path,
+                                  "value": nnz / (ms_path * 1e-3), "ratio_to_timed_path": round(ms_path / ms_per_step, 4)}
+            fuse = paths[args.path]
+            x.grad = ar.grad = ac.grad = None
         if (world == 1 and not use_pg and not args.force_dist and not args.simulate_rank and args.workload != "cora"
                 and not args.no_other_labels):
             # the same step on the other labelling of the same graph (continuity with round 1,

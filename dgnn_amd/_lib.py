@@ -28,6 +28,7 @@ SIGNATURES = {
     "dgnn_error_string": (ctypes.c_char_p, [_i]),
     "dgnn_debug_last_kernel_ms": (_i, [_i, _vp]),
     "dgnn_debug_last_kernel_name": (ctypes.c_char_p, [_i]),
+    "dgnn_debug_kernel_launches": (ctypes.c_longlong, [_i]),
     "dgnn_gat_forward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_gat_forward": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 11 + [_vp, _sz, _vp]),
     "dgnn_gat_forward_noalloc": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 9 + [_vp]),
@@ -45,6 +46,9 @@ SIGNATURES = {
     "dgnn_gat_backward_seeded": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_u64, _u64] + [_vp] * 11 + [_vp, _sz, _vp]),
     "dgnn_gat_forward_seeded_dev": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_vp] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_gat_backward_seeded_dev": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 7 + [_vp] + [_vp] * 11 + [_vp, _sz, _vp]),
+    "dgnn_gat_saved_floats": (_sz, [_i, _i, _i]),
+    "dgnn_gat_forward_saved": (_i, [_i, _i, _i, _i, _f, _f] + [_vp] * 5 + [_u64, _u64] + [_vp] * 4 + [_vp, _sz, _vp]),
+    "dgnn_gat_backward_saved": (_i, [_i, _i, _i, _i, _i, _f, _f] + [_vp] * 15 + [_vp, _sz, _vp]),
     "dgnn_spmm_csr_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dgnn_spmm_csr": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp, _sz, _vp]),
     "dgnn_mhsddmm": (_i, [_i, _i, _i, _i] + [_vp] * 5 + [_vp]),
@@ -155,6 +159,13 @@ def last_kernel_ms(which):
     ms = ctypes.c_float(0.0)
     rc = lib().dgnn_debug_last_kernel_ms(int(which), ctypes.byref(ms))
     return float(ms.value) if rc == 0 else None
+
+
+def kernel_launches(which):
+    """Launches of the forward (0) / backward (1) gather kernel since the library was loaded; None
+    when timing is off (DGNN_TIMING=1 before the library is loaded)."""
+    v = lib().dgnn_debug_kernel_launches(int(which))
+    return int(v) if v >= 0 else None
 
 
 def last_kernel_name(which):

@@ -143,7 +143,7 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
                    const float *attn_row, const float *attn_col, const int *row_ptr,
                    const int *col_ind, const float *in_feat, const float *edge_mask,
                    float *edge_max, float *edge_sum, float *out_feat, void *workspace,
-                   size_t workspace_bytes, hipStream_t st, DropRng rng, float *out_neg, float *a_neg) {
+                   size_t workspace_bytes, hipStream_t st, DropRng rng, float *out_neg, float *a_neg, float *out2) {
   if (m == 0) return DGNN_OK;
   if ((out_neg == nullptr) != (a_neg == nullptr)) return DGNN_ERR_BAD_ARG;
   if (out_neg != nullptr && (!edge_max || !edge_sum)) return DGNN_ERR_BAD_ARG;
@@ -157,7 +157,7 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
     P.row_ptr = row_ptr; P.col_ind = col_ind;
     P.attn_row = attn_row; P.attn_col = attn_col; P.edge_mask = edge_mask; P.rng = rng;
     P.in_feat = in_feat; P.edge_max = edge_max; P.edge_sum = edge_sum; P.out = out_feat;
-    P.out_neg = out_neg; P.a_neg = a_neg;
+    P.out_neg = out_neg; P.a_neg = a_neg; P.out2 = out_neg != nullptr ? out2 : nullptr;
     return launch_fast_gather<MODE_GAT>(P, workspace, workspace_bytes, st);
   }
   if (out_neg != nullptr) return DGNN_ERR_UNSUPPORTED;   // the wave-per-row kernels have no negative-score pair
@@ -201,6 +201,11 @@ int dgnn_debug_phase_cycles(unsigned long long *out16, int reset) {
   return DGNN_OK;
 }
 #endif
+
+long long dgnn_debug_kernel_launches(int which) {
+  if (which < 0 || which > 1 || !timing_on()) return -1;
+  return g_timer.launches[which];
+}
 
 const char *dgnn_debug_last_kernel_name(int which) {
   if (which < 0 || which > 1 || !timing_on() || !g_timer.valid[which]) return nullptr;
@@ -438,6 +443,43 @@ int dgnn_gat_forward_seeded_dev(int m, int nnz, int h, int f, float attn_drop, f
                         a_neg);
 }
 
+
+// ------------------------------------------------- forward state carried in the edge_mask slot
+__global__ void k_write_rng_pair(unsigned long long seed, unsigned long long offset, unsigned long long *dst) {
+  dst[0] = seed;
+  dst[1] = offset;
+}
+
+size_t dgnn_gat_saved_floats(int m, int h, int f) {
+  if (m < 0 || h <= 0 || f <= 0) return 0;
+  return saved_layout(m, h, f).total;
+}
+
+int dgnn_gat_forward_saved(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                           const float *attn_row, const float *attn_col, const int *row_ptr,
+                           const int *col_ind, const float *in_feat, uint64_t seed, uint64_t offset,
+                           float *edge_max, float *edge_sum, float *out_feat, float *saved, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+  int rc = check_dims(m, nnz, h, f);
+  if (rc) return rc;
+  if (m == 0) return DGNN_OK;
+  if (!attn_row || !row_ptr || !out_feat || !edge_max || !edge_sum || !saved) return DGNN_ERR_BAD_ARG;
+  if (nnz > 0 && (!attn_col || !in_feat || !col_ind)) return DGNN_ERR_BAD_ARG;
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return DGNN_ERR_BAD_ARG;
+  if (!aligned16(saved)) return DGNN_ERR_ALIGNMENT;
+  // the pair exists on the neighbour-grouped float4 kernels only; elsewhere the caller keeps a mask
+  if (!fwd_fast_ok(m, h) || f < 4) return DGNN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < fwd_layout(nnz, h, f, true).total) return DGNN_ERR_WORKSPACE;
+  const SavedLayout w = saved_layout(m, h, f);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_write_rng_pair, dim3(1), dim3(1), 0, st, (unsigned long long)seed, (unsigned long long)offset,
+                     (unsigned long long *)saved);
+  DGNN_LAUNCH_CHECK();
+  return launch_forward(m, nnz, h, f, attn_drop, negative_slope, attn_row, attn_col, row_ptr, col_ind, in_feat,
+                        nullptr, edge_max, edge_sum, out_feat, workspace, workspace_bytes, st,
+                        DropRng{seed, offset, attn_drop > 0.f ? 1 : 0, nullptr}, saved + w.off_neg, saved + w.off_aneg,
+                        saved + w.off_out);
+}
 
 // ------------------------------------------------------------------------- GE-SpMM / GMM
 size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f) {

@@ -417,6 +417,27 @@ int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float nega
                            DropRng{0, 0, 1, (const unsigned long long *)rng_state}, out_neg, a_neg);
 }
 
+int dgnn_gat_backward_saved(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
+                            const int *row_ptr, const int *col_ind, const int *col_ptr,
+                            const int *row_ind, const int *permute, const float *edge_max,
+                            const float *edge_sum, const float *saved, const float *in_feat,
+                            const float *attn_row, const float *attn_col, const float *grad,
+                            float *grad_feat, float *grad_attn_row, float *grad_attn_col, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  if (m > 0 && (!saved || !aligned16(saved))) return DGNN_ERR_BAD_ARG;
+  if (m <= 0 || h <= 0 || f <= 0)
+    return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
+                             edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, nullptr, nullptr, nullptr,
+                             grad_feat, grad_attn_row, grad_attn_col, workspace, workspace_bytes, stream);
+  const SavedLayout w = saved_layout(m, h, f);
+  // the dropout pair the forward wrote in front of the saved rows is read by the kernels themselves
+  return gat_backward_impl(m, n, nnz, h, f, negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute,
+                           edge_max, edge_sum, nullptr, in_feat, attn_row, attn_col, grad, saved + w.off_out, nullptr,
+                           nullptr, grad_feat, grad_attn_row, grad_attn_col, workspace, workspace_bytes, stream,
+                           DropRng{0, 0, attn_drop > 0.f ? 1 : 0, (const unsigned long long *)saved}, saved + w.off_neg,
+                           saved + w.off_aneg);
+}
+
 int dgnn_gat_backward_seeded(int m, int n, int nnz, int h, int f, float negative_slope,
                              float attn_drop, const int *row_ptr, const int *col_ind,
                              const int *col_ptr, const int *row_ind, const int *permute,

@@ -73,6 +73,9 @@ struct GatherParams {
   // because sum_j a_j g_j sl_j = S - (1-slope) sum_{e_j<0} a_j g_j and sum_j a_j sl_j = 1 - (1-slope) A_neg.
   float *out_neg;                    // [m,H,F]  sum over the edges with e_j < 0 of w_j * in_feat[c_j]
   float *a_neg;                      // [m,H]    sum over the edges with e_j < 0 of the softmax weight (no mask)
+  float *out2;                       // optional second copy of `out` (NEG instantiations only): the copy the
+                                     // reference-signature path keeps for the backward (dgnn_gat_forward_saved),
+                                     // written by the same lanes as `out` -- one more store, no copy pass
   int slot_neg;                      // float offset of the out_neg partial inside a slot
   int *task_row0;                    // [T] row that contains edge t*L
   float *slots;                      // [2T][slot_stride]
@@ -136,6 +139,8 @@ __global__ void k_fast_prep_rows(GatherParams P) {
       const int width = P.sum_heads ? P.F : P.HF;
       float *o = P.out + (size_t)r * width;
       for (int i = 0; i < width; ++i) o[i] = 0.f;
+      if (P.out2 != nullptr)
+        for (int i = 0; i < P.HF; ++i) P.out2[(size_t)r * P.HF + i] = 0.f;
       if (P.out_neg != nullptr) {
         for (int i = 0; i < P.HF; ++i) P.out_neg[(size_t)r * P.HF + i] = 0.f;
         for (int h = 0; h < P.H; ++h) P.a_neg[(size_t)r * P.H + h] = 0.f;
@@ -806,6 +811,7 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
             float *dst = (d >= 0) ? P.out + (size_t)d * P.HF : P.slots + (size_t)(-(d + 1)) * P.slot_stride;
             if (active && g == 0) st4u(dst + lane_off, acc);
             if constexpr (NEG) {
+              if (P.out2 != nullptr && d >= 0 && active && g == 0) st4u(P.out2 + (size_t)d * P.HF + lane_off, acc);
               float *dn = (d >= 0) ? P.out_neg + (size_t)d * P.HF
                                    : P.slots + (size_t)(-(d + 1)) * P.slot_stride + P.slot_neg;
               if (active && g == 0) st4u(dn + lane_off, accn);
@@ -914,6 +920,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           if (active[s]) V::store(dst + lane_off[s], acc[s]);
+          if constexpr (NEG) {
+            if (P.out2 != nullptr && d >= 0 && active[s]) V::store(P.out2 + (size_t)d * P.HF + lane_off[s], acc[s]);
+          }
           acc[s] = V::zero();
         }
         if constexpr (NEG) {
@@ -1060,6 +1069,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                   if (active[s]) V::store(dst + lane_off[s], acc[s]);
+                  if constexpr (NEG) {
+                    if (P.out2 != nullptr && d >= 0 && active[s]) V::store(P.out2 + (size_t)d * P.HF + lane_off[s], acc[s]);
+                  }
                   acc[s] = V::zero();
                 }
                 if constexpr (NEG) {
@@ -1243,6 +1255,8 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_fixup(GatherParams P, int p
           st4u(P.out + (size_t)r * P.HF + fid, make_float4(acc[0] / S, acc[1] / S, acc[2] / S, acc[3] / S));
         else
           P.out[(size_t)r * P.HF + fid] = acc[0] / S;
+        if (vec4 && P.out2 != nullptr)
+          st4u(P.out2 + (size_t)r * P.HF + fid, make_float4(acc[0] / S, acc[1] / S, acc[2] / S, acc[3] / S));
         if (P.edge_max != nullptr && first_of_head) {
           P.edge_max[(size_t)r * H + head] = M;
           P.edge_sum[(size_t)r * H + head] = S;

@@ -28,6 +28,7 @@ struct KernelTimer {
   bool on = false, init = false;
   hipEvent_t ev[2][2];
   bool valid[2] = {false, false};
+  long long launches[2] = {0, 0};  // launches of the timed kernel since the library was loaded
   char name[2][96] = {{0}, {0}};   // template instantiation of the kernel last timed, as rocprofv3 prints it
 };
 extern KernelTimer g_timer;      // defined in gather.hip
@@ -45,7 +46,10 @@ inline bool timing_on() {
 inline void timer_mark(int which, int edge, hipStream_t st) {
   if (timing_on()) {
     (void)hipEventRecord(g_timer.ev[which][edge], st);
-    if (edge == 1) g_timer.valid[which] = true;
+    if (edge == 1) {
+      g_timer.valid[which] = true;
+      ++g_timer.launches[which];
+    }
   }
 }
 
@@ -88,7 +92,22 @@ int launch_forward(int m, int nnz, int h, int f, float attn_drop, float slope,
                    const int *col_ind, const float *in_feat, const float *edge_mask,
                    float *edge_max, float *edge_sum, float *out_feat, void *workspace,
                    size_t workspace_bytes, hipStream_t st, DropRng rng = DropRng{0, 0, 0, nullptr},
-                   float *out_neg = nullptr, float *a_neg = nullptr);
+                   float *out_neg = nullptr, float *a_neg = nullptr, float *out2 = nullptr);
+
+// Layout (in floats) of the buffer the reference-signature path carries from forward to backward in
+// the slot of the reference's edge_mask (include/dgnn_hip.h: dgnn_gat_forward_saved)
+struct SavedLayout {
+  size_t off_out, off_neg, off_aneg, total;
+};
+inline SavedLayout saved_layout(int m, int h, int f) {
+  SavedLayout w;
+  const size_t mhf = align_up((size_t)m * h * f, 4), mh = align_up((size_t)m * h, 4);
+  w.off_out = 4;                      // [0, 4): the dropout {seed, offset} pair, two uint64
+  w.off_neg = w.off_out + mhf;
+  w.off_aneg = w.off_neg + mhf;
+  w.total = w.off_aneg + mh;
+  return w;
+}
 
 }  // namespace host
 }  // namespace dgnn

@@ -163,14 +163,44 @@ GatDims check_gat_fwd(const Tensor &attn_row, const Tensor &attn_col, const Tens
 }
 
 // -> [out_feat, edge_max, edge_sum, edge_mask]   (fused_gatconv.cpp:11-32)
+// DGNN_REF_SAVED=0: the reference-signature calls keep a materialised mask (round-2 behaviour)
+bool ref_saved_enabled() {
+  const char *e = std::getenv("DGNN_REF_SAVED");
+  return !(e != nullptr && e[0] == '0');
+}
+
 std::vector<Tensor> gat_forward(const Tensor &attn_row, const Tensor &attn_col, const Tensor &row_ptr,
                                 const Tensor &col_ind, double negative_slope, const Tensor &in_feat,
-                                double attn_drop, const OptTensor &edge_mask_in, const OutList &outs, bool neg) {
+                                double attn_drop, const OptTensor &edge_mask_in, const OutList &outs, bool neg,
+                                bool saved) {
   const GatDims d = check_gat_fwd(attn_row, attn_col, row_ptr, col_ind, in_feat);
   c10::DeviceGuard guard(in_feat.device());
   Tensor out = out_f32(outs, 0, {d.m, d.h, d.f}, in_feat, "out_feat");
   Tensor edge_max = out_f32(outs, 1, {d.m, d.h}, in_feat, "edge_max");
   Tensor edge_sum = out_f32(outs, 2, {d.m, d.h}, in_feat, "edge_sum");
+  // The reference's own wrapper (dgNN/operators/fused_gatconv.py:16-29) keeps the fourth result and hands
+  // it back to gat_backward untouched; nobody else reads it.  A plain call with the reference's seven
+  // arguments therefore gets in that slot, instead of an [nnz,h] mask, the 1-D tensor dgnn_gat_forward_saved
+  // fills (a copy of out_feat, the negative-score pair and the dropout seed): gat_backward recognises it
+  // by its shape and runs the one-pass backward -- no rebuilt forward, no mask.  saved=False, an explicit
+  // edge_mask, or DGNN_REF_SAVED=0 give the mask of round 2.
+  if (saved && !neg && !given(edge_mask_in) && !outs.has_value() && d.m > 0 && d.f >= 4 && d.h <= 8 &&
+      ref_saved_enabled()) {
+    uint64_t seed = 0;
+    if (attn_drop > 0.0)      // torch's CPU generator: reproducible under torch.manual_seed, no device sync
+      seed = (uint64_t)at::randint(0, (int64_t)1 << 62, {1}, at::TensorOptions().dtype(at::kLong)).item<int64_t>();
+    Tensor carrier = new_f32({(int64_t)API(dgnn_gat_saved_floats)(d.m, d.h, d.f)}, in_feat);
+    const size_t nb = API(dgnn_gat_forward_workspace_bytes)(d.m, d.nnz, d.h, d.f);
+    Tensor ws = workspace(nb, in_feat);
+    const int rc = API(dgnn_gat_forward_saved)(d.m, d.nnz, d.h, d.f, (float)attn_drop, (float)negative_slope,
+                                               fp(attn_row), fp(attn_col), ip(row_ptr), ip(col_ind), fp(in_feat), seed,
+                                               (uint64_t)0, fo(edge_max), fo(edge_sum), fo(out), fo(carrier),
+                                               ptr<void>(ws), nb, stream_of(in_feat));
+    if (rc != DGNN_ERR_UNSUPPORTED) {
+      check_rc(rc, "dgnn_gat_forward_saved");
+      return {out, edge_max, edge_sum, carrier};
+    }
+  }
   Tensor edge_mask;
   if (attn_drop > 0.0) {
     // the reference draws the mask with cuRAND on every call (fused_gatconv_kernel.cu:333-341)
@@ -319,6 +349,26 @@ std::vector<Tensor> gat_backward(double negative_slope, double attn_drop, const 
   const int n = as_int(col_ptr.size(0) - 1, "columns");
   const int h = as_int(in_feat.size(1), "heads"), f = as_int(in_feat.size(2), "features");   // :1049-1050
   check_neg_pair(out_neg, a_neg, grad);
+  // the tensor gat_forward returned in the edge_mask slot of the reference signature (see there): 1-D,
+  // exactly dgnn_gat_saved_floats(m, h, f) long -- a mask is [nnz, h]
+  if (given(edge_mask) && edge_mask->dim() == 1 && m > 0 &&
+      edge_mask->numel() == (int64_t)API(dgnn_gat_saved_floats)(m, h, f) && !given(out_neg)) {
+    f32(*edge_mask, "edge_mask (saved forward state)", 1);
+    if (in_feat.size(0) != n || attn_col.size(0) != n) fail("gat_backward: in_feat/attn_col rows must equal len(col_ptr)-1");
+    if (grad.size(0) != m || grad.size(1) != h || grad.size(2) != f) fail("gat_backward: grad must be [m,h,f]");
+    c10::DeviceGuard guard(in_feat.device());
+    Tensor grad_feat = out_f32(outs, 0, {n, h, f}, in_feat, "grad_feat");
+    Tensor grad_attn_row = out_f32(outs, 1, {m, h}, in_feat, "grad_attn_row");
+    Tensor grad_attn_col = out_f32(outs, 2, {n, h}, in_feat, "grad_attn_col");
+    const size_t nb = API(dgnn_gat_backward_workspace_bytes)(m, n, nnz, h, f, 1);
+    Tensor ws = workspace(nb, in_feat);
+    check_rc(API(dgnn_gat_backward_saved)(m, n, nnz, h, f, (float)negative_slope, (float)attn_drop, ip(row_ptr),
+                                          ip(col_ind), ip(col_ptr), ip(row_ind), ip(permute), fp(edge_max), fp(edge_sum),
+                                          fp(*edge_mask), fp(in_feat), fp(attn_row), fp(attn_col), fp(grad), fo(grad_feat),
+                                          fo(grad_attn_row), fo(grad_attn_col), ptr<void>(ws), nb, stream_of(in_feat)),
+             "dgnn_gat_backward_saved");
+    return {grad_feat, grad_attn_row, grad_attn_col};
+  }
   if (in_feat.size(0) != n || attn_col.size(0) != n)
     fail("gat_backward: in_feat/attn_col rows must equal len(col_ptr)-1");
   if (grad.size(0) != m || attn_row.size(0) != m || edge_max.size(0) != m || edge_sum.size(0) != m)
@@ -957,12 +1007,15 @@ PYBIND11_MODULE(fused_gatconv, m) {
   options.disable_function_signatures();
   init(m, "Drop-in for the reference's pybind module fused_gatconv (fused_gatconv.cpp:168-174).");
   def(m, "gat_forward", &gat_forward,
-      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask=None, out=None",
-      "-> [out_feat, edge_max, edge_sum, edge_mask]   (fused_gatconv.cpp:11-32).  The mask is drawn with torch's\n"
-      "generator only when attn_drop > 0 (empty tensor otherwise); edge_mask may be passed explicitly (tests).\n"
+      "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask=None, out=None, neg=False, saved=True",
+      "-> [out_feat, edge_max, edge_sum, edge_mask]   (fused_gatconv.cpp:11-32).  Called with the reference's seven\n"
+      "arguments the fourth result is the forward state gat_backward wants back in its edge_mask argument (a 1-D\n"
+      "tensor: copy of out_feat, negative-score pair, dropout seed -- no [nnz,h] mask is drawn or kept).  saved=False or\n"
+      "an explicit edge_mask: the mask itself, drawn with torch's generator only when attn_drop > 0.\n"
       "out = (out_feat, edge_max, edge_sum), entries may be None: write into these tensors instead of new ones.",
       arg("attn_row"), arg("attn_col"), arg("row_ptr"), arg("col_ind"), arg("negative_slope"), arg("in_feat"),
-      arg("attn_drop"), arg("edge_mask") = py::none(), arg("out") = py::none(), arg("neg") = false);
+      arg("attn_drop"), arg("edge_mask") = py::none(), arg("out") = py::none(), arg("neg") = false,
+      arg("saved") = true);
   def(m, "gat_forward_tb", &gat_forward_tb,
       "attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, tile_scheduler, tile=32",
       "-> [out_feat, edge_max, edge_sum]   (fused_gatconv.cpp:68-95).  tile_scheduler must be the list the\n"

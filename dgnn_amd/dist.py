@@ -77,7 +77,7 @@ class _NativeOps:
         out = (out, edge_max, edge_sum[, None, out_neg, a_neg]) views to write into."""
         if not neg:
             out, emax, esum, _ = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0,
-                                                       out=out)
+                                                       out=out, saved=False)
             return out, emax, esum
         res = self._gat.gat_forward(attn_row, attn_col, row_ptr, col_ind, slope, in_feat, 0.0, out=out, neg=True)
         return res[0], res[1], res[2], res[4], res[5]

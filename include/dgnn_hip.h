@@ -52,6 +52,9 @@ int dgnn_debug_last_kernel_ms(int which, float *ms);
  * "k_bwd_col_gather<4, 4, 4, 0, false>" (so a counter profile of another instantiation is not
  * mistaken for this kernel's).  NULL when timing is off or nothing was launched yet. */
 const char *dgnn_debug_last_kernel_name(int which);
+/* How many times that kernel has been launched since the library was loaded (-1 when timing is
+ * off): lets a test assert that a backward did NOT rebuild the forward. */
+long long dgnn_debug_kernel_launches(int which);
 
 /* ------------------------------------------------------------------ fused GAT ---- */
 
@@ -254,6 +257,35 @@ int dgnn_gat_backward_seeded_dev(int m, int n, int nnz, int h, int f, float nega
                                  const float *out_neg, const float *a_neg,
                                  float *grad_feat, float *grad_attn_row, float *grad_attn_col,
                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* The forward -> backward hand-over of a caller that keeps the REFERENCE'S OWN signatures.  The
+ * reference's wrapper saves what gat_forward returns in its fourth slot -- the [nnz,h] edge_mask -- and
+ * hands it back to gat_backward untouched (dgNN/operators/fused_gatconv.py:16-29; launchers
+ * fused_gatconv_kernel.cu:322-361 and :998-1038); nobody else reads it.  Here that slot carries
+ * `saved`, dgnn_gat_saved_floats(m, h, f) floats (16-byte aligned):
+ *   [0, 4)                 the dropout {seed, offset} pair as two uint64, written by the forward
+ *   [4, 4 + mhf')          a second copy of out_feat, written by the lanes that write out_feat itself
+ *   [.., + mhf')           out_neg          [.., + mh')   a_neg          (x' = x rounded up to 4)
+ * so that dgnn_gat_backward_saved runs the one-pass backward of dgnn_gat_backward(out_feat, out_neg,
+ * a_neg) -- no rebuilt forward, no [nnz,h] edge gradients, and at attn_drop > 0 no 4 * nnz * h byte
+ * mask: both passes regenerate it from the pair (as dgnn_gat_*_seeded_dev).  Same bits as the
+ * dgnn_gat_forward_seeded / dgnn_gat_backward_seeded pair with (out_feat, out_neg, a_neg).
+ * DGNN_ERR_UNSUPPORTED (nothing launched) for shapes outside the neighbour-grouped float4 kernels
+ * (more than 8 heads, fewer than 4 features): such callers keep a materialised mask. */
+size_t dgnn_gat_saved_floats(int m, int h, int f);
+int dgnn_gat_forward_saved(int m, int nnz, int h, int f, float attn_drop, float negative_slope,
+                           const float *attn_row, const float *attn_col, const int *row_ptr,
+                           const int *col_ind, const float *in_feat, uint64_t seed, uint64_t offset,
+                           float *edge_max, float *edge_sum, float *out_feat, float *saved,
+                           void *workspace, size_t workspace_bytes, void *stream);
+/* workspace: dgnn_gat_backward_workspace_bytes(m, n, nnz, h, f, 1) */
+int dgnn_gat_backward_saved(int m, int n, int nnz, int h, int f, float negative_slope, float attn_drop,
+                            const int *row_ptr, const int *col_ind, const int *col_ptr,
+                            const int *row_ind, const int *permute, const float *edge_max,
+                            const float *edge_sum, const float *saved, const float *in_feat,
+                            const float *attn_row, const float *attn_col, const float *grad,
+                            float *grad_feat, float *grad_attn_row, float *grad_attn_col,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------- GE-SpMM / SDDMM / permute ---- */
 

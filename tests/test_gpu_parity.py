@@ -22,6 +22,8 @@ GRAPHS = named_graphs()
 GRAPHS["rmat4k"] = rmat_graph(12, 4000, 60000, 7)      # hubs: rows/columns with 1000+ entries
 
 DEV = "cuda:0"
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from dgnn_amd import _lib  # noqa: E402  (ctypes view of the C ABI: workspace / saved-state size queries)
 
 # DGNN_FUZZ_EXTRA=N: N more seeds for the degree-pattern fuzz tests (and N/4 for the hub fuzz), for a
 # longer hunt after a kernel change; the committed suite runs the base seeds only.
@@ -69,8 +71,11 @@ def test_gat_forward_backward(nat, name, h, f, p):
     d_in, d_ar, d_ac, d_grad = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
     d_mask = dev(mask) if mask is not None else None
 
+    # saved=False: the mask form of the fourth result (explicit masks, the edge-gradient backward and
+    # the backward that rebuilds out_feat); the saved-state form of the plain reference call has
+    # its own test, test_gat_reference_signature_hands_the_forward_state_through_the_mask_slot
     out, emax, esum, emask = nat["gat"].gat_forward(d_ar, d_ac, G["row_ptr"], G["col_ind"], slope,
-                                                    d_in, p, edge_mask=d_mask)
+                                                    d_in, p, edge_mask=d_mask, saved=False)
     o64, m64, s64 = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope,
                                            in_feat, p, mask)
     m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p)
@@ -1321,3 +1326,96 @@ def test_gat_feature_rows_at_any_dword_alignment(nat, h, f):
     assert_close(host(base[3]), gf64, "any alignment: grad_feat", mass=m_gf)
     assert_close(host(base[4]), gr64, "any alignment: grad_attn_row", mass=m_gr)
     assert_close(host(base[5]), gc64, "any alignment: grad_attn_col", mass=m_gc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "deg_edges", "powerlaw256", "rmat4k"])
+@pytest.mark.parametrize("h,f", [(4, 64), (1, 16), (8, 8), (4, 41), (1, 7), (2, 100), (9, 8), (2, 3)])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_gat_reference_signature_hands_the_forward_state_through_the_mask_slot(nat, name, h, f, p):
+    """The reference's wrapper calls gat_forward with seven positional arguments, keeps the fourth
+    result and passes it back as gat_backward's edge_mask (dgNN/operators/fused_gatconv.py:16-29).
+    That slot carries the forward state (copy of out_feat, negative-score pair, dropout seed): the
+    backward with the reference's fourteen positional arguments is then the one-pass backward.
+    Checked against the float64 oracle; under dropout with the mask the seed in the slot expands to.
+    Shapes outside the pair's kernels (nine heads, three features) keep a mask and still work."""
+    g = GRAPHS[name]
+    G = gdev(g)
+    slope = 0.2
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=41)
+    x, ar, ac, go = dev(in_feat), dev(attn_row), dev(attn_col), dev(grad)
+    torch.manual_seed(1234)
+    res = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], slope, x, p)                    # fused_gatconv.py:16
+    assert len(res) == 4
+    out, emax, esum, slot = res
+    fast = h <= 8 and f >= 4
+    mask = None
+    if fast:
+        want = _lib.lib().dgnn_gat_saved_floats(g["n"], h, f)
+        assert slot.dim() == 1 and slot.numel() == want, "the saved forward state, not a mask"
+        if p > 0:
+            seed = int(slot[:4].view(torch.int64)[0].item())
+            assert int(slot[:4].view(torch.int64)[1].item()) == 0 and 0 <= seed < (1 << 62)
+            mask = host(nat["gat"].dropout_mask(g["nnz"], h, seed, 0, x))
+        # the copy in the slot is out_feat itself
+        assert torch.equal(slot[4:4 + g["n"] * h * f].view(g["n"], h, f), out)
+    else:
+        assert tuple(slot.shape) == ((g["nnz"], h) if p > 0 else (0, h))
+        mask = host(slot) if p > 0 else None
+    out_before = out.clone()
+    out.mul_(3.0)             # the caller may do what it likes with ITS out_feat (the reference saves none)
+    gf, gr, gc = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                         emax, esum, slot, x, ar, ac, go)                             # fused_gatconv.py:28-29
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], slope, in_feat, p, mask)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(slope, p, g["row_ptr"], g["col_ind"], mask, in_feat, attn_row, attn_col, grad)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, slope, p)
+    assert_close(host(out_before), o64, "reference signature: out_feat", mass=m_out)
+    assert_close(host(gf), gf64, "reference signature: grad_feat", mass=m_gf)
+    assert_close(host(gr), gr64, "reference signature: grad_attn_row", mass=m_gr)
+    assert_close(host(gc), gc64, "reference signature: grad_attn_col", mass=m_gc)
+    if fast and p == 0:
+        # bit for bit the operator's own path (explicit pair)
+        o2, em2, es2, _, on2, an2 = nat["gat"].gat_forward(ar, ac, G["row_ptr"], G["col_ind"], slope, x, p, neg=True)
+        ref = nat["gat"].gat_backward(slope, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"],
+                                      em2, es2, None, x, ar, ac, go, out_feat=o2, out_neg=on2, a_neg=an2)
+        assert torch.equal(o2, out_before)
+        for u, v in zip((gf, gr, gc), ref):
+            assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_gat_reference_signature_backward_launches_no_second_forward():
+    """through the reference's signature the backward used to rebuild out_feat with a whole
+    extra forward.  With the kernel counters of the library (DGNN_TIMING=1, a fresh process): one
+    forward launch and one backward launch per step, through the reference's OWN wrapper code path
+    (same positional arguments)."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from util import rmat_graph, gat_inputs
+from dgnn_amd import _lib
+from dgnn_amd.native import fused_gatconv as fg
+g = rmat_graph(12, 4000, 60000, 7)
+dev = "cuda:0"
+G = {k: torch.from_numpy(g[k]).to(dev) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute")}
+x, ar, ac, go = (torch.from_numpy(t).to(dev) for t in gat_inputs(g["n"], 4, 64, 0))
+for p in (0.0, 0.5):
+    f0, b0 = _lib.kernel_launches(0), _lib.kernel_launches(1)
+    out, emax, esum, mask = fg.gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p)
+    fg.gat_backward(0.2, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], emax, esum, mask, x, ar, ac, go)
+    torch.cuda.synchronize()
+    print("launches", p, _lib.kernel_launches(0) - f0, _lib.kernel_launches(1) - b0)
+    # the round-2 form of the same call (a mask in the slot): the backward rebuilds the forward
+    f0 = _lib.kernel_launches(0)
+    out, emax, esum, mask = fg.gat_forward(ar, ac, G["row_ptr"], G["col_ind"], 0.2, x, p, saved=False)
+    fg.gat_backward(0.2, p, G["row_ptr"], G["col_ind"], G["col_ptr"], G["row_ind"], G["permute"], emax, esum, mask, x, ar, ac, go)
+    torch.cuda.synchronize()
+    print("mask form", p, _lib.kernel_launches(0) - f0)
+""" % (ROOT_DIR, ROOT_DIR)
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, DGNN_TIMING="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "launches 0.0 1 1" in r.stdout and "launches 0.5 1 1" in r.stdout, r.stdout
+    assert "mask form 0.0 2" in r.stdout and "mask form 0.5 2" in r.stdout, r.stdout
