@@ -40,6 +40,7 @@ H, F = 4, 64
 SLOPE = 0.2
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # collectives of a bench run take milliseconds: a rank that waits this long has lost a peer
+TORCH_THREADS = torch.get_num_threads()     # (read at start-up: loading the OpenMP oracle later changes what torch reports)
 PG_TIMEOUT = __import__("datetime").timedelta(seconds=int(os.environ.get("DGNN_PG_TIMEOUT", "120")))
 
 
@@ -203,7 +204,6 @@ def cpu_baseline(name, seed=0):
     g = rmat_graph(sc, ns, max(es - ns, 1), seed)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], H, F, seed)
     cores = min(oracle.max_threads(), 16)
-    torch_threads = torch.get_num_threads()          # (read before the oracle changes the OpenMP setting)
     oracle.set_threads(cores)
     t0 = time.perf_counter()
     out, emax, esum = oracle.gat_forward(attn_row, attn_col, g["row_ptr"], g["col_ind"], SLOPE, in_feat, 0.0)
@@ -212,9 +212,240 @@ def cpu_baseline(name, seed=0):
     dt = time.perf_counter() - t0
     oracle.set_threads(1)
     return {"value": g["nnz"] / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
-            "cpu_count": os.cpu_count(), "torch_threads": torch_threads,
+            "cpu_count": os.cpu_count(), "torch_threads": TORCH_THREADS,
             "sample": f"oracle f32 fwd+bwd on a 1/{div} scale R-MAT of the same shape "
                       f"(n={g['n']}, nnz={g['nnz']}, {H}x{F}), {dt:.2f} s wall"}
+
+
+# ---------------------------------------------------------------------------------------------
+# The other BASELINE.json configurations (configs[1]: fused GMMConv on a PubMed-shaped graph, also on
+# the Reddit shape of test/gmm_result.csv:10; configs[2]: fused EdgeConv on a ModelNet40-shaped batch),
+# same JSON schema.  Algorithmic bytes: SURVEY.md section 8(d) "EdgeConv / GMM algorithmic bytes".
+GMM_K, GMM_D, GMM_F = 3, 2, 64            # test/gmm_result.csv:6 (hidden 64; the script's default is 16)
+DGCNN = dict(batch=32, points=2048, k=20, dims=((3, 64), (64, 64), (64, 128), (128, 256)))   # train_edgeconv.py:244
+
+
+def _events():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def _time_steps(step_fn, steps, warmup, sync):
+    for _ in range(warmup):
+        step_fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    return time.perf_counter() - t0
+
+
+def _host_info():
+    return {"cpu": cpu_model(), "torch_threads": TORCH_THREADS, "cpu_count": os.cpu_count()}
+
+
+def bench_gmm(args, device):
+    """A step = GmmConvFuse forward + backward (autograd operator) over the whole graph."""
+    import dgnn_amd  # noqa: F401
+    from dgnn_amd import _lib
+    from dgnn_amd.graph import prepare_graph
+    from dgnn_amd.operators import GmmConvFuse
+    K, D, F = GMM_K, GMM_D, GMM_F
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    if args.workload == "gmm-pubmed":
+        n, e = 19_717, 88_648                  # SURVEY.md 8(d) C2: directed edges, + one self loop per node
+        src = torch.randint(0, n, (e,), device=device, generator=gen)
+        dst = torch.randint(0, n, (e,), device=device, generator=gen)
+        row_ptr, col_ind, col_ptr, row_ind, permute = prepare_graph(src, dst, n, "replace")
+        shape = f"PubMed-shaped random graph (test/gmm_result.csv:6), n={n}"
+    else:
+        g = build_graph("reddit", device, seed=0, labels=args.labels)
+        n = g["n"]
+        row_ptr, col_ind, col_ptr, row_ind, permute = (g[k] for k in ("row_ptr", "col_ind", "col_ptr", "row_ind", "permute"))
+        shape = f"Reddit-shaped R-MAT (test/gmm_result.csv:10), n={n}, node labels {args.labels}"
+    nnz = int(col_ind.numel())
+    # pseudo coordinates of the reference's MoNet script (train_gmmconv.py:120-122): 1/sqrt(deg) of both ends
+    deg = (row_ptr[1:] - row_ptr[:-1]).float().clamp_(min=1)
+    row_of = torch.repeat_interleave(torch.arange(n, device=device), (row_ptr[1:] - row_ptr[:-1]).long())
+    pseudo = torch.stack([deg[col_ind.long()].rsqrt(), deg[row_of].rsqrt()], 1).contiguous().requires_grad_()
+    del row_of
+    x = torch.randn((n, K, F), device=device, generator=gen).requires_grad_()
+    mu = (0.1 * torch.randn((K, D), device=device, generator=gen)).requires_grad_()     # gmmconv_layer.py:48-49
+    sg = torch.ones((K, D), device=device).requires_grad_()
+    go = torch.randn((n, K, F), device=device, generator=gen)
+
+    def step_fn():
+        x.grad = pseudo.grad = mu.grad = sg.grad = None
+        GmmConvFuse(row_ptr, col_ind, col_ptr, row_ind, permute, x, pseudo, mu, sg).backward(go)
+
+    torch.cuda.reset_peak_memory_stats(device)
+    steps = args.steps if args.workload != "gmm-pubmed" else max(args.steps, 200)     # 50-us steps: time many
+    dt = _time_steps(step_fn, steps, args.warmup, torch.cuda.synchronize)
+    ms = dt / steps * 1e3
+    peak = round(torch.cuda.max_memory_allocated(device) / 2**20)
+    kf, kb = _lib.last_kernel_ms(0) or 0.0, _lib.last_kernel_ms(1) or 0.0
+    b_fwd = nnz * (4 + 4 * D + 4 * K * F) + n * (4 * K * F + 4)
+    # the one-pass backward: grad row gather + row_ind + permute + pseudo through permute + grad_gauss scatter per
+    # edge; the column's own node_feat row, grad_feat row and pointer per node
+    b_bwd = nnz * (4 * K * F + 8 + 4 * D + 4 * K) + n * (8 * K * F + 4)
+    b_survey = nnz * (2 * (4 + 4 * D + 4 * K * F) + 8 * K + 12 * D + 4) + n * 12 * K * F     # the reference's three kernels
+    name, nbytes, kms = (_lib.last_kernel_name(1), b_bwd, kb) if kb >= kf else (_lib.last_kernel_name(0), b_fwd, kf)
+    roof = None
+    if kms > 0:
+        ach = nbytes / (kms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": name, "kernel_instance": name, "algorithmic_bytes": nbytes, "kernel_ms": round(kms, 4),
+                "fwd_kernel_ms": round(kf, 4), "bwd_kernel_ms": round(kb, 4),
+                "survey_reference_3kernel_backward_bytes": b_survey}
+        if n * K * F * 4 <= 256 << 20:
+            roof["note"] = ("feature table %.0f MB fits L2 / Infinity Cache: frac is against the HBM peak although the rows "
+                            "come from cache" % (n * K * F * 4 / 1e6)) + \
+                           ("; kernels of ~20 us: the step is launch-bound, not bandwidth-bound" if nnz < 1_000_000 else "")
+    line = {"metric": "GMMConv fwd+bwd edges/s", "value": nnz / (ms * 1e-3), "unit": "edges/s", "n_gpus": 1, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "peak_mem_MB": peak, "host": _host_info(),
+            "config": {"workload": f"fused GmmConvFuse fwd+bwd, {shape}, nnz={nnz}, kernels={K}, pseudo_dim={D}, feat={F}",
+                       "parallelism": "single GPU"}}
+    if roof:
+        line["roofline"] = roof
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_gmm(n, nnz, row_ptr, col_ind, col_ptr, row_ind, permute, pseudo)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_baseline_gmm(n, nnz, row_ptr, col_ind, col_ptr, row_ind, permute, pseudo):
+    """Oracle port of the reference's GMM step on the host: gmmconv forward, mhsddmm + gmmconv on the CSC +
+    GaussianBp backward (dgNN/operators/fused_gmmconv.py:14-27).  PubMed shape: the whole graph; Reddit
+    shape: the first rows holding ~1/64 of the edges (a bounded sample)."""
+    import oracle
+    K, D, F = GMM_K, GMM_D, GMM_F
+    rp = row_ptr.cpu().numpy()
+    rows = n if nnz <= 2_000_000 else int(np.searchsorted(rp, nnz // 64))
+    e = int(rp[rows])
+    sub_rp, sub_ci = rp[:rows + 1].copy(), col_ind[:e].cpu().numpy()
+    ps = pseudo.detach()[:e].cpu().numpy()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, K, F)).astype(np.float32)
+    go = rng.standard_normal((rows, K, F)).astype(np.float32)
+    mu = (0.1 * rng.standard_normal((K, D))).astype(np.float32)
+    sg = np.ones((K, D), np.float32)
+    cores = min(oracle.max_threads(), 16)
+    oracle.set_threads(cores)
+    cp, ri, pm = oracle.csr2csc(sub_rp, sub_ci, n)
+    t0 = time.perf_counter()
+    oracle.gmmconv(sub_rp, sub_ci, x, ps, mu, sg)
+    gg = oracle.mhsddmm(sub_rp, sub_ci, go, x)
+    oracle.gmmconv(cp, ri, go, oracle.mhtranspose(pm, ps), mu, sg)
+    oracle.gaussian_bp(ps, mu, sg, gg)
+    dt = time.perf_counter() - t0
+    oracle.set_threads(1)
+    return {"value": e / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu": cpu_model(), "cpu_count": os.cpu_count(),
+            "torch_threads": TORCH_THREADS,
+            "sample": f"oracle f32 GMM fwd + three-call bwd on {rows} rows / {e} edges of the same graph, {dt:.2f} s wall"}
+
+
+def bench_dgcnn(args, device, world, rank, json_fd=None):
+    """A step = the four EdgeConv layers of DGCNN (train_edgeconv.py:43-70) as the fused path sees them: per
+    layer the k-NN graph in the layer's input space, then EdgeConvFuse forward + backward at the layer's
+    width.  Data parallel over clouds (replicas only): every rank steps on its own 32
+    clouds, no data-path collective; value = edges of all ranks / slowest rank."""
+    import dgnn_amd  # noqa: F401
+    from dgnn_amd import _lib
+    from dgnn_amd.native.knn import knn_graph
+    from dgnn_amd.operators import EdgeConvFuse
+    B, P, k = DGCNN["batch"], DGCNN["points"], DGCNN["k"]
+    m = B * P
+    gen = torch.Generator(device=device)
+    gen.manual_seed(rank)
+    layers = []
+    for din, f in DGCNN["dims"]:
+        xin = torch.randn((B, P, din), device=device, generator=gen)
+        if din > 3:                       # feature spaces sit behind an activation: positive, off-centre
+            xin = torch.nn.functional.leaky_relu(xin + 1.0, 0.2)
+        layers.append(dict(x=xin, hs=torch.randn((m, f), device=device, generator=gen).requires_grad_(),
+                           hd=torch.randn((m, f), device=device, generator=gen).requires_grad_(),
+                           go=torch.randn((m, f), device=device, generator=gen), f=f, src=None))
+
+    def step_fn(with_knn=True):
+        for L in layers:
+            if with_knn or L["src"] is None:
+                L["src"] = knn_graph(L["x"], k)
+            L["hs"].grad = L["hd"].grad = None
+            EdgeConvFuse(k, L["src"], L["hs"], L["hd"]).backward(L["go"])
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    torch.cuda.reset_peak_memory_stats(device)
+    steps = max(args.steps, 50)
+    dt = _time_steps(step_fn, steps, args.warmup, sync)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / steps * 1e3
+    peak = round(torch.cuda.max_memory_allocated(device) / 2**20)
+    ms_noknn = _time_steps(lambda: step_fn(False), steps, 2, torch.cuda.synchronize) / steps * 1e3
+    # dominant EdgeConv kernel: the forward at the widest layer, event-timed by the library
+    per = []
+    for L in layers:
+        EdgeConvFuse(k, L["src"], L["hs"], L["hd"]).backward(L["go"])
+        torch.cuda.synchronize()
+        per.append((L["f"], _lib.last_kernel_ms(0) or 0.0, _lib.last_kernel_ms(1) or 0.0, _lib.last_kernel_name(0)))
+    f_dom, kf, kb, kname = max(per, key=lambda t: t[1])
+    nbytes = m * (4 * k + 4 * k * f_dom + 4 * f_dom + 8 * f_dom)
+    edges = 4 * m * k * world
+    if rank != 0:
+        return
+    line = {"metric": "EdgeConv fwd+bwd edges/s", "value": edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "peak_mem_MB": peak, "host": _host_info(),
+            "config": {"workload": f"DGCNN EdgeConv stack on a ModelNet40-shaped batch: {B} clouds x {P} points per GPU, k={k}, "
+                                   f"widths {[d[1] for d in DGCNN['dims']]}, k-NN graph rebuilt per layer in dims "
+                                   f"{[d[0] for d in DGCNN['dims']]} (INCLUDED in the step), fused EdgeConvFuse fwd+bwd",
+                       "parallelism": "single GPU" if world == 1 else f"data parallel over clouds x{world} (replicas, no data-path collective)"},
+            "knn_excluded": {"ms_per_step": round(ms_noknn, 4), "value": 4 * m * k / (ms_noknn * 1e-3),
+                             "note": "rank 0 alone, graphs reused: the four EdgeConvFuse fwd+bwd only"},
+            "per_layer_kernel_ms": [{"feat": f, "fwd": round(a, 4), "bwd_gather": round(b, 4)} for f, a, b, _ in per]}
+    if kf > 0:
+        ach = nbytes / (kf * 1e-3) / 1e9
+        line["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": f"{kname} at feat={f_dom}",
+                            "kernel_instance": kname, "algorithmic_bytes": nbytes, "kernel_ms": round(kf, 4),
+                            "note": "a point's neighbours lie in its own cloud (2 MB of rows at 256 features): the gather is "
+                                    "served by L2, so frac against the HBM peak exceeds 1 by design"}
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_dgcnn()
+    if json_fd is None:
+        print(json.dumps(line), flush=True)
+    else:                                  # fd 1 points at stderr while RCCL may print its banner (see main)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
+def cpu_baseline_dgcnn():
+    """Oracle port on the host: k-NN graph + EdgeConv forward / backward of the four layers on a bounded
+    sample of 2 clouds."""
+    import oracle
+    B, P, k = 2, DGCNN["points"], DGCNN["k"]
+    rng = np.random.default_rng(0)
+    cores = min(oracle.max_threads(), 16)
+    oracle.set_threads(cores)
+    t0 = time.perf_counter()
+    for din, f in DGCNN["dims"]:
+        x = rng.standard_normal((B, P, din)).astype(np.float32)
+        src = oracle.knn_graph(x, k)
+        hs, hd = (rng.standard_normal((B * P, f)).astype(np.float32) for _ in range(2))
+        out, idx = oracle.edgeconv_forward(k, src, hs, hd)
+        oracle.edgeconv_backward(out, idx.astype(np.int32))
+    dt = time.perf_counter() - t0
+    oracle.set_threads(1)
+    return {"value": 4 * B * P * k / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "cpu_count": os.cpu_count(), "torch_threads": TORCH_THREADS,
+            "sample": f"oracle k-NN + EdgeConv fwd+bwd of the four layers on {B} clouds x {P} points, {dt:.2f} s wall "
+                      "(array generation included)"}
 
 
 def self_launch(n_ranks, argv):
@@ -305,7 +536,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="products", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="products", choices=list(WORKLOADS) + ["gmm-pubmed", "gmm-reddit", "dgcnn"],
+                    help="products (default, the headline), reddit, cora: fused GAT; gmm-pubmed / gmm-reddit: fused "
+                         "GMMConv (BASELINE configs[1]); dgcnn: fused EdgeConv stack with k-NN (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--labels", default="scrambled", choices=["scrambled", "natural"],
                     help="node ids of the R-MAT graph: scrambled = after the load-time relabelling of "
@@ -354,6 +587,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=PG_TIMEOUT)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
+
+    if args.workload in ("gmm-pubmed", "gmm-reddit"):
+        if world > 1:
+            print("bench.py: the GMMConv workloads are single-GPU configurations (BASELINE.json configs[1])", file=sys.stderr)
+            sys.exit(2)
+        return bench_gmm(args, device)
+    if args.workload == "dgcnn":
+        bench_dgcnn(args, device, world, rank, json_fd)
+        if use_pg:
+            torch.distributed.destroy_process_group()
+        return
 
     import dgnn_amd  # noqa: F401
     from dgnn_amd.operators import GATConvFuse
@@ -540,7 +784,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "peak_mem_MB": peak_mem_mb,
-            "host": {"cpu": cpu_model(), "torch_threads": torch.get_num_threads(), "cpu_count": os.cpu_count()},
+            "host": {"cpu": cpu_model(), "torch_threads": TORCH_THREADS, "cpu_count": os.cpu_count()},
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
                                    f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd, node labels {args.labels}"
                                    + (" (load-time relabelling, dgnn_amd.graph.relabel_nodes)" if args.labels == "scrambled" else ""),

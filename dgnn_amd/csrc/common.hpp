@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/dgnn_hip.h"
 
@@ -274,6 +276,47 @@ static __device__ unsigned long long g_phase_cycles[2][8];
 #define DGNN_PHASE_DECL() do { } while (0)
 #define DGNN_PHASE_MARK(kernel, phase) do { } while (0)
 #endif
+
+namespace host {
+// Optional timing of the dominant kernels (DGNN_TIMING=1): HIP events recorded on the launch stream
+// right around the kernel, read back with dgnn_debug_last_kernel_ms().  Slot 0 = the forward-side
+// kernel launched last (row gather of the fused GAT / SpMM / GMMConv forward, fused EdgeConv forward),
+// slot 1 = the backward-side one (column gather of the GAT / GMMConv backward, EdgeConv backward
+// gather).  Off by default; this is the only process-global state in the library and it never
+// changes results.
+struct KernelTimer {
+  bool on = false, init = false;
+  hipEvent_t ev[2][2];
+  bool valid[2] = {false, false};
+  long long launches[2] = {0, 0};  // launches of the timed kernel since the library was loaded
+  char name[2][96] = {{0}, {0}};   // template instantiation of the kernel last timed, as rocprofv3 prints it
+};
+extern KernelTimer g_timer;      // defined in gather.hip
+inline bool timing_on() {
+  if (!g_timer.init) {
+    g_timer.init = true;
+    { const char *e = getenv("DGNN_TIMING"); g_timer.on = e != nullptr && e[0] != 0 && atoi(e) != 0; }
+    if (g_timer.on)
+      for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 2; ++i)
+          if (hipEventCreate(&g_timer.ev[k][i]) != hipSuccess) g_timer.on = false;
+  }
+  return g_timer.on;
+}
+inline void timer_name(int which, const char *name) {
+  if (timing_on()) snprintf(g_timer.name[which], sizeof(g_timer.name[which]), "%s", name);
+}
+inline void timer_mark(int which, int edge, hipStream_t st) {
+  if (timing_on()) {
+    (void)hipEventRecord(g_timer.ev[which][edge], st);
+    if (edge == 1) {
+      g_timer.valid[which] = true;
+      ++g_timer.launches[which];
+    }
+  }
+}
+
+}  // namespace host
 
 static inline int blocks_for_waves(long long n_waves) {
   return (int)((n_waves + DGNN_WAVES_PER_BLOCK - 1) / DGNN_WAVES_PER_BLOCK);

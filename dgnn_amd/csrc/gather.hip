@@ -83,7 +83,7 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   // DGNN_FWD_LDS_PAD: extra dynamic LDS per workgroup = an occupancy limiter for tuning runs
   const size_t lds = fast_lds_bytes(P.H, P.L, P.pack_s > 0) + (size_t)env_int("DGNN_FWD_LDS_PAD", 0);
   const dim3 grid(blocks_for_waves(P.T));
-  if (MODE == MODE_GAT) timer_mark(0, 0, st);
+  timer_mark(0, 0, st);
   // vector slots per lane: one walk over the edges for rows up to 64 / 128 / 256 slots
   const int ns = P.rowv <= DGNN_WAVE ? 1 : P.rowv <= 2 * DGNN_WAVE ? 2 : 4;
   const bool steady = P.steady != 0;
@@ -101,7 +101,7 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
     ht = 4;
 #define DGNN_FWD_CASE(VECV, NSV, HTV, STV)                                                     \
   if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV && steady == STV) {                     \
-    if (MODE == MODE_GAT && timing_on())                                                       \
+    if (timing_on())                                                                           \
       std::snprintf(g_timer.name[0], sizeof(g_timer.name[0]), "k_fast_row_gather<%d, %d, %d, %d, %s, %s, %d>", MODE, \
                     VECV, NSV, HTV, STV ? "true" : "false", (MODE == MODE_GAT && VECV == 4 && neg) ? "true" : "false", \
                     (STV && NSV == 1 && VECV == 4) ? P.pack_s : 0);                            \
@@ -121,7 +121,7 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   }
 #undef DGNN_FWD_CASES
 #undef DGNN_FWD_CASE
-  if (MODE == MODE_GAT) timer_mark(0, 1, st);
+  timer_mark(0, 1, st);
   DGNN_LAUNCH_CHECK();
   if (P.T > 1) {
     // two launches: long rows first merge groups of DGNN_FIX_C pieces (phase 0), then everything (phase 1)

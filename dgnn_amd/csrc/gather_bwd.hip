@@ -119,7 +119,7 @@ void launch_bwd_gather(const BwdParams &P, int hc, int vec, dim3 grid, dim3 bloc
   const int pk = (vec == 4) ? bwd_stream_kind(P, hc) : 0;
 #define DGNN_BWD_CASE(HC, EPL)                                                                    \
   if (hc == HC && P.L == 64 * EPL) {                                                              \
-    if (BMODE == BWD_GAT && timing_on())                                                          \
+    if (timing_on())                                                                              \
       std::snprintf(g_timer.name[1], sizeof(g_timer.name[1]), "k_bwd_col_gather<%d, %d, %d, %d, %s, %d>", HC, EPL, \
                     vec == 4 ? 4 : 1, BMODE, (vec == 4 && P.steady) ? "true" : "false", pk);      \
     if (vec == 4 && P.steady)                                                                     \
@@ -531,7 +531,9 @@ static int gmm_backward_impl(int nodes, int nnz, int kernels, int dim, int embed
   }
   if (P.T > 0) {
     const dim3 grid(blocks_for_waves(P.T)), block(DGNN_BLOCK);
+    timer_mark(1, 0, st);
     launch_bwd_gather<BWD_GMM>(P, hc, vec, grid, block, bwd_lds_bytes(hc, P.L, P.hreg != 0), st);
+    timer_mark(1, 1, st);
     DGNN_LAUNCH_CHECK();
     if (P.T > 1) {
       if (vec == 4)

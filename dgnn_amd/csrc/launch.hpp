@@ -21,38 +21,6 @@ inline bool force_generic() {
   return e != nullptr && e[0] == '1';
 }
 
-// Optional timing of the two dominant kernels (DGNN_TIMING=1): HIP events recorded on the launch
-// stream right around the kernel, read back with dgnn_debug_last_kernel_ms().  Off by default;
-// this is the only process-global state in the library and it never changes results.
-struct KernelTimer {
-  bool on = false, init = false;
-  hipEvent_t ev[2][2];
-  bool valid[2] = {false, false};
-  long long launches[2] = {0, 0};  // launches of the timed kernel since the library was loaded
-  char name[2][96] = {{0}, {0}};   // template instantiation of the kernel last timed, as rocprofv3 prints it
-};
-extern KernelTimer g_timer;      // defined in gather.hip
-inline bool timing_on() {
-  if (!g_timer.init) {
-    g_timer.init = true;
-    g_timer.on = env_int("DGNN_TIMING", 0) != 0;
-    if (g_timer.on)
-      for (int k = 0; k < 2; ++k)
-        for (int i = 0; i < 2; ++i)
-          if (hipEventCreate(&g_timer.ev[k][i]) != hipSuccess) g_timer.on = false;
-  }
-  return g_timer.on;
-}
-inline void timer_mark(int which, int edge, hipStream_t st) {
-  if (timing_on()) {
-    (void)hipEventRecord(g_timer.ev[which][edge], st);
-    if (edge == 1) {
-      g_timer.valid[which] = true;
-      ++g_timer.launches[which];
-    }
-  }
-}
-
 // ----------------------------------------------------------------------------- forward side
 struct FwdLayout {
   int L, T, slot_stride, slot_neg;

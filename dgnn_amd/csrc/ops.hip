@@ -748,14 +748,19 @@ int dgnn_edgeconv_forward(int m, int f, int k, const int *src_ind, const float *
     int lp = 16;                 // at least 16 lanes per point: two registers then hold a 32-neighbour tile's ids
     while (lp < f / 4 && lp < DGNN_WAVE) lp <<= 1;
     const long long waves = ((long long)m + DGNN_WAVE / lp - 1) / (DGNN_WAVE / lp);
+    host::timer_name(0, "k_edgeconv_fwd4");
+    host::timer_mark(0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(k_edgeconv_fwd4, dim3(blocks_for_waves(waves)), dim3(DGNN_BLOCK), 0,
                        (hipStream_t)stream, m, f, k, lp, src_ind, h_src, h_dst, out_feat, max_idx_f32,
                        max_idx_i32, edgeconv_xcd());
   } else {
+    host::timer_name(0, "k_edgeconv_fwd");
+    host::timer_mark(0, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(k_edgeconv_fwd, dim3(blocks_for_waves(m)), dim3(DGNN_BLOCK), 0,
                        (hipStream_t)stream, m, f, k, src_ind, h_src, h_dst, out_feat, max_idx_f32,
                        max_idx_i32, edgeconv_xcd());
   }
+  host::timer_mark(0, 1, (hipStream_t)stream);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }
@@ -806,12 +811,15 @@ int dgnn_edgeconv_backward_det(int m, int f, int k, const int *src_ind, const in
   const bool vec4 = (f % 4 == 0) && ((((uintptr_t)max_idx | (uintptr_t)grad_out | (uintptr_t)grad_src) & 15u) == 0);
   const int slots = vec4 ? f / 4 : f;
   const long long total = (long long)m * slots;
+  host::timer_name(1, vec4 ? "k_edgeconv_bwd_gather<4>" : "k_edgeconv_bwd_gather<1>");
+  host::timer_mark(1, 0, st);
   if (vec4)
     hipLaunchKernelGGL(k_edgeconv_bwd_gather<4>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
                        col_ptr, row_ind, max_idx, grad_out, grad_src, edgeconv_xcd());
   else
     hipLaunchKernelGGL(k_edgeconv_bwd_gather<1>, dim3(grid_1d(total, 256)), dim3(256), 0, st, total, slots, f,
                        col_ptr, row_ind, max_idx, grad_out, grad_src, edgeconv_xcd());
+  host::timer_mark(1, 1, st);
   DGNN_LAUNCH_CHECK();
   return DGNN_OK;
 }
