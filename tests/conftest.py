@@ -42,12 +42,20 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         return
     rows = {k: {"elements": v[0], "outside_plain_band": v[1], "worst_err_over_plain_tol": round(v[2], 3),
                 "rtol": v[3], "atol": v[4]} for k, v in sorted(TOLERANCE_TALLY.items())}
+    try:
+        from util import LITERAL_TALLY
+        for k, v in LITERAL_TALLY.items():      # the reference's own float32 arithmetic on the same inputs
+            rows[k]["literal_f32_worst_err_over_plain_tol"] = round(v, 3)
+    except Exception:  # pragma: no cover
+        pass
     leaning = {k: v for k, v in rows.items() if v["outside_plain_band"]}
     terminalreporter.write_line(f"tolerance tally: {len(rows)} labelled checks, {len(leaning)} with elements "
                                 f"outside the plain band (passing through the mass term)")
     for k, v in leaning.items():
         terminalreporter.write_line(f"  {k}: {v['outside_plain_band']} / {v['elements']} outside rel {v['rtol']:g} "
-                                    f"abs {v['atol']:g}, worst {v['worst_err_over_plain_tol']}x")
+                                    f"abs {v['atol']:g}, worst {v['worst_err_over_plain_tol']}x"
+                                    + (f" (literal float32 on the same inputs: {v['literal_f32_worst_err_over_plain_tol']}x)"
+                                       if "literal_f32_worst_err_over_plain_tol" in v else ""))
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)

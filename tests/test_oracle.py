@@ -13,8 +13,9 @@ import scipy.sparse as sp
 import torch
 
 import oracle
-from util import (ATOL, RTOL, assert_close, gat_inputs, gat_masses, gaussian_bp_masses, named_graphs, random_graph,
-                  rmat_graph, tiny_graph)
+from util import (ATOL, RTOL, LITERAL_TALLY, assert_close, gat_inputs, gat_masses, gaussian_bp_masses, gmm_case,
+                  named_graphs, parity_graphs, random_graph, rmat_graph, spmm_case, tiny_graph,
+                  GMM_GRAPHS, GMM_SHAPES, GMM_SUM_GRAPHS, GMM_SUM_SHAPES, SPMM_GRAPHS, SPMM_SHAPES)
 
 GRAPHS = named_graphs()
 
@@ -242,6 +243,59 @@ def test_reference_arithmetic_needs_mass_term_on_hubs():
     strict_bad = sum(int((np.abs(a - b) > ATOL + RTOL * np.abs(b)).sum())
                      for a, b in ((gf32, gf64), (gr32, gr64), (gc32, gc64)))
     assert strict_bad > 0, "expected the plain band to be too tight for the reference's own float32 sums"
+
+
+def test_literal_float32_tally_on_the_inputs_of_the_gpu_tests():
+    """the literal float32 restatement of the reference's SpMM / SDDMM / GMM
+    arithmetic against the float64 oracle on EXACTLY the inputs of the GPU parity tests
+    (util.spmm_case / gmm_case over the same graphs and shapes), same plain band, same mass term.
+    The worst literal error per label (x the plain tolerance) lands in LITERAL_TALLY under the GPU
+    tests' labels -- the terminal summary prints it, and the GPU tests hold HIP's worst to
+    max(1, 2 x this) (tests/test_gpu_parity.py, test_zz_hip_error_within_twice_the_reference_arithmetic)."""
+    G = parity_graphs()
+    for name in SPMM_GRAPHS:
+        g = G[name]
+        rp, ci = g["row_ptr"], g["col_ind"]
+        for h, f in SPMM_SHAPES:
+            val, a, b = spmm_case(g, h, f)
+            lit = oracle.spmm_csr(rp, ci, val, b)
+            assert_close(lit, oracle.spmm_csr_f64(rp, ci, val, b), "spmm", literal=lit,
+                         mass=oracle.spmm_csr_f64(rp, ci, np.abs(val), np.abs(b)))
+            lit = oracle.mhsddmm(rp, ci, a, b)
+            assert_close(lit, oracle.mhsddmm_f64(rp, ci, a, b), "sddmm", literal=lit,
+                         mass=oracle.mhsddmm_f64(rp, ci, np.abs(a), np.abs(b)))
+    for name in GMM_GRAPHS:
+        g = G[name]
+        rp, ci, cp, ri = g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"]
+        for k, d, f in GMM_SHAPES:
+            x, ps, mu, sg, gg, grad = gmm_case(g, k, d, f)
+            lit = oracle.gmmconv(rp, ci, x, ps, mu, sg)
+            assert_close(lit, oracle.gmmconv_f64(rp, ci, x, ps, mu, sg), "gmm forward", literal=lit,
+                         mass=oracle.gmmconv_f64(rp, ci, np.abs(x), ps, mu, sg))
+            psc = ps[g["permute"]]
+            lit = oracle.gmmconv(cp, ri, grad, psc, mu, sg)
+            assert_close(lit, oracle.gmmconv_f64(cp, ri, grad, psc, mu, sg), "fused gmm backward: grad_node_feat",
+                         literal=lit, mass=oracle.gmmconv_f64(cp, ri, np.abs(grad), psc, mu, sg))
+            lit = oracle.mhsddmm(rp, ci, grad, x)
+            assert_close(lit, oracle.mhsddmm_f64(rp, ci, grad, x), "fused gmm backward: grad_gauss", literal=lit,
+                         mass=oracle.mhsddmm_f64(rp, ci, np.abs(grad), np.abs(x)))
+    for name in GMM_SUM_GRAPHS:
+        g = G[name]
+        rp, ci, cp, ri = g["row_ptr"], g["col_ind"], g["col_ptr"], g["row_ind"]
+        for k, f in GMM_SUM_SHAPES:
+            x, ps, mu, sg, _, go = gmm_case(g, k, 2, f, seed=k * 10 + f, grad_per_kernel=False)
+            go_k = np.repeat(go[:, None, :], k, 1)
+            psc = ps[g["permute"]]
+            lit = oracle.gmmconv(rp, ci, x, ps, mu, sg).sum(1, dtype=np.float32)
+            assert_close(lit, oracle.gmmconv_f64(rp, ci, x, ps, mu, sg).sum(1), "GmmConvFuseSum: out", literal=lit,
+                         mass=oracle.gmmconv_f64(rp, ci, np.abs(x), ps, mu, sg).sum(1))
+            lit = oracle.gmmconv(cp, ri, go_k, psc, mu, sg)
+            assert_close(lit, oracle.gmmconv_f64(cp, ri, go_k, psc, mu, sg), "GmmConvFuseSum: grad node_feat",
+                         literal=lit, mass=oracle.gmmconv_f64(cp, ri, np.abs(go_k), psc, mu, sg))
+    assert set(LITERAL_TALLY) >= {"spmm", "sddmm", "gmm forward", "fused gmm backward: grad_node_feat",
+                                  "fused gmm backward: grad_gauss", "GmmConvFuseSum: out",
+                                  "GmmConvFuseSum: grad node_feat"}
+    print("literal float32 worst error / plain tolerance:", {k: round(v, 3) for k, v in sorted(LITERAL_TALLY.items())})
 
 
 # ----------------------------------------------------------------------------- k-NN graph
