@@ -39,6 +39,9 @@ WORKLOADS = {
 H, F = 4, 64
 SLOPE = 0.2
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# measured single-GPU steps (scrambled labels, profiles/r3h_bench_line_products.json, r3i_bench_line_reddit.json):
+# the denominator of the "expected" multi-GPU curve
+SINGLE_GPU_MS = {"products": 21.85, "reddit": 29.4}
 # collectives of a bench run take milliseconds: a rank that waits this long has lost a peer
 TORCH_THREADS = torch.get_num_threads()     # (read at start-up: loading the OpenMP oracle later changes what torch reports)
 PG_TIMEOUT = __import__("datetime").timedelta(seconds=int(os.environ.get("DGNN_PG_TIMEOUT", "120")))
@@ -633,8 +636,7 @@ def main():
         from dgnn_amd.dist import PartitionedGAT
         if args.simulate_rank:
             sim_r, sim_n = (int(v) for v in args.simulate_rank.split("/"))
-            runner = PartitionedGAT(g, sim_n, sim_r, device, fake_peers=True,
-                                    chunks=int(os.environ.get("DGNN_DIST_CHUNKS", "4")))
+            runner = PartitionedGAT(g, sim_n, sim_r, device, fake_peers=True)    # chunks: DGNN_DIST_CHUNKS or the plan's
         else:
             runner = PartitionedGAT(g, world, rank, device)
         lo, hi = runner.lo, runner.hi
@@ -794,6 +796,14 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+        if use_pg or args.force_dist or args.simulate_rank:
+            # a PREDICTION of this step over real links (dgnn_amd.dist.PartitionedGAT.expected_ms): the curve a
+            # multi-GPU record is to be judged against; speedup against the measured single-GPU step
+            exp = runner.expected_ms(H, F)
+            exp["single_gpu_ms_per_step"] = SINGLE_GPU_MS.get(args.workload)
+            if exp["single_gpu_ms_per_step"]:
+                exp["speedup_over_one_gpu"] = round(exp["single_gpu_ms_per_step"] / exp["ms_per_step"], 2)
+            line["expected"] = exp
         if args.simulate_rank:
             line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
                                  f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")

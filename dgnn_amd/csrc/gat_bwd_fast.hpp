@@ -240,8 +240,13 @@ __global__ void k_bwd_prep_cols(BwdParams P) {
 // Until round 3 every narrow kernel held all of these side by side and the register allocation was
 // the union of their lane constants: 102 VGPRs = four waves per SIMD at one head; one stream per
 // kernel takes 65 = seven waves, and these kernels are bound by the latencies a wave cannot hide.
+#ifdef DGNN_BWD_WPE      // A/B builds: cap the waves per SIMD of the column gather (tools/ab_shapes.sh)
+#define DGNN_BWD_OCC __attribute__((amdgpu_waves_per_eu(1, DGNN_BWD_WPE)))
+#else
+#define DGNN_BWD_OCC
+#endif
 template <int HC, int EPL, int VEC, int BMODE, bool STEADY, int PK = 0>
-__global__ __launch_bounds__(DGNN_BLOCK) void k_bwd_col_gather(BwdParams P) {
+__global__ __launch_bounds__(DGNN_BLOCK) DGNN_BWD_OCC void k_bwd_col_gather(BwdParams P) {
   static_assert(PK == 0 || (STEADY && VEC == 4), "the packed streams exist in the narrow float4 instantiations only");
   using V = VecT<VEC>;
   using vec_t = typename V::type;

@@ -18,7 +18,11 @@ The reference is single-GPU only; this is new d
   the forward on an (n_loc x n_halo) rectangle, the backward on an (n_halo x n_loc) rectangle.
 
 Exchange (``mode``):
-  "halo" (default)  only the rows a rank actually references move, and own rows never travel:
+  "auto" (default)  "halo" unless every rank references >= 90 % of the remote rows (then
+                    "allgather"); chunk count and shape from the wire / compute ratio of the
+                    partition (PartitionedGAT._plan: 4 geometric chunks when compute-bound, 8 equal
+                    chunks when wire-bound, e.g. two ranks over one link).
+  "halo"            only the rows a rank actually references move, and own rows never travel:
                     index lists are exchanged once at set-up; the block is processed in S chunks
                     (``DGNN_DIST_CHUNKS``, default 4) of consecutive rows (forward) / columns
                     (backward), smallest first; chunk s fetches only the remote rows no earlier
@@ -110,13 +114,27 @@ class _NativeOps:
         return self._fmt.csr2csc_int(ptr, ind, n_cols=n_cols)
 
 
-def chunk_fractions(chunks):
-    """Shares of a block's edges given to its chunks: 1/2^(S-1), 1/2^(S-1), 1/2^(S-2), ..., 1/2.
-    The FIRST exchange cannot be hidden behind compute, so the first chunk is the smallest; on a
-    power-law graph it still pulls in the hubs (~1/4 of the halo for 1/16 of the edges)."""
+def chunk_fractions(chunks, shape="geometric"):
+    """Shares of a block's edges given to its chunks.
+    "geometric" (compute-bound pipelines): 1/2^(S-1), 1/2^(S-1), 1/2^(S-2), ..., 1/2.  The FIRST
+    exchange cannot be hidden behind compute, so the first chunk is the smallest; on a power-law
+    graph it still pulls in the hubs (~1/4 of the halo for 1/16 of the edges).
+    "equal" (wire-bound pipelines, e.g. two ranks over ONE xGMI link): the wire never idles, what
+    stays exposed is the compute of the LAST chunk behind the last message, so no chunk is large."""
     if chunks <= 1:
         return [1.0]
+    if shape == "equal":
+        return [1.0 / chunks] * chunks
     return [0.5 ** (chunks - 1)] + [0.5 ** (chunks - i) for i in range(1, chunks)]
+
+
+# The two rates the exchange plan and bench.py's "expected" curve are priced with (DESIGN.md section 6).
+# LINK: what one xGMI link delivers to an all-to-all message in one direction (153 GB/s peak per link,
+# MI355X_MICROARCH.md; ~2/3 of it assumed achievable by RCCL's point-to-point sends) -- an ASSUMPTION until
+# the first multi-GPU record exists.  GATHER: the rate at which one rank's kernels consume gathered rows,
+# measured on one GPU (products shape: 62 M edges x 1 KiB x 2 passes in 21.9 ms).
+LINK_GBS = float(os.environ.get("DGNN_DIST_LINK_GBS", "100"))
+GATHER_GBS = float(os.environ.get("DGNN_DIST_GATHER_GBS", "5800"))
 
 
 class _NoWait:
@@ -165,14 +183,14 @@ class _Side:
     arrived and the exchange of chunk s+1 runs while chunk s computes.  Own rows never travel.
     """
 
-    def __init__(self, owner, ptr, ind, chunks):
+    def __init__(self, owner, ptr, ind, chunks, shape="geometric"):
         dev = ind.device
         n, lo, hi, n_loc = owner.n, owner.lo, owner.hi, owner.n_loc
         ptr = ptr.to(torch.int64)
         ind = ind.to(torch.int64)
         nnz = int(ptr[-1]) if ptr.numel() else 0
         acc, cuts = 0.0, [0]
-        for fr in chunk_fractions(chunks)[:-1]:
+        for fr in chunk_fractions(chunks, shape)[:-1]:
             acc += fr
             cuts.append(int(torch.searchsorted(ptr, torch.tensor([int(acc * nnz)], device=dev))[0]))
         cuts.append(n_loc)
@@ -232,7 +250,7 @@ class PartitionedGAT:
                  fake_peers=False):
         self.world, self.rank, self.device, self.group = world, rank, device, group
         self.ops = ops if ops is not None else _NativeOps()
-        self.mode = mode or os.environ.get("DGNN_DIST_MODE", "halo")
+        self.mode = mode or os.environ.get("DGNN_DIST_MODE", "auto")
         # one rank needs no collectives; DGNN_DIST_FORCE_COLLECTIVES=1 issues them anyway (a
         # single-GPU rehearsal of the RCCL calls: tests/test_dist.py)
         self._solo = world == 1 and os.environ.get("DGNN_DIST_FORCE_COLLECTIVES") != "1"
@@ -242,11 +260,10 @@ class PartitionedGAT:
         self._fake_peers = bool(fake_peers)
         if self._fake_peers:
             self._solo = True
-        if self.mode not in ("halo", "allgather"):
+        if self.mode not in ("auto", "halo", "allgather"):
             raise ValueError(f"unknown exchange mode {self.mode!r}")
-        if chunks is None:
-            chunks = int(os.environ.get("DGNN_DIST_CHUNKS", "4" if world > 1 else "1"))
-        self.chunks = max(1, int(chunks)) if self.mode == "halo" else 1
+        if chunks is None and "DGNN_DIST_CHUNKS" in os.environ:
+            chunks = int(os.environ["DGNN_DIST_CHUNKS"])
         row_ptr, col_ind = graph["row_ptr"], graph["col_ind"]
         col_ptr, row_ind = graph["col_ptr"], graph["row_ind"]
         self.n = row_ptr.numel() - 1
@@ -262,9 +279,11 @@ class PartitionedGAT:
         b_ptr = col_ptr[lo:hi + 1] - col_ptr[lo]
         b_row = row_ind[c0:c1].contiguous()
         self.nnz_fwd, self.nnz_bwd = e1 - e0, c1 - c0
+        self.plan = self._plan(f_col, chunks)
+        self.mode, self.chunks, shape = self.plan["mode"], self.plan["chunks"], self.plan["chunk_shape"]
         if self.mode == "halo":
-            self.f_side = _Side(self, f_ptr, f_col, self.chunks)
-            self.b_side = _Side(self, b_ptr, b_row, self.chunks)
+            self.f_side = _Side(self, f_ptr, f_col, self.chunks, shape)
+            self.b_side = _Side(self, b_ptr, b_row, self.chunks, shape)
             b_blocks = self.b_side.blocks
         else:
             self.f_row_ptr = f_ptr.to(torch.int32).contiguous()
@@ -285,6 +304,87 @@ class PartitionedGAT:
         self._ctx = None
         self._tables = {}
         self._pair_agreed = {}      # (heads, features) -> every rank's forward produced the negative-score pair
+
+    # ------------------------------------------------------------------ exchange plan
+    def _plan(self, f_col, chunks):
+        """Which exchange this partition gets.  Two numbers of the rank's forward block decide, both
+        independent of the row width: ``halo_fraction`` = distinct remote rows referenced / remote
+        rows that exist, and ``wire_over_compute`` = time the halo spends on the wire (its rows
+        spread over world-1 links at LINK_GBS) / time the rank's kernels spend gathering the
+        block's edges (GATHER_GBS).  Every rank must issue the same collectives, so the ranks take
+        the MAX of the ratio and the MIN of the fraction over the group (one all-reduce at set-up).
+          * DGNN_DIST_MODE=auto (default): "allgather" when every rank references >=
+            DGNN_DIST_ALLGATHER_ABOVE (0.9) of the remote rows -- the halo lists, packs and
+            relabelled tables then buy nothing over two plain all-gathers; "halo" otherwise.
+          * chunks (when neither the argument nor DGNN_DIST_CHUNKS fixes them): compute-bound
+            (ratio <= 1, e.g. products on 8 or 4 ranks) -> 4 geometric chunks, the small first
+            chunk bounds the exposed exchange; wire-bound (ratio > 1, e.g. products on 2 ranks:
+            56 % of the other half over ONE link) -> 8 equal chunks, the exchange is the critical
+            path from the first byte and what can still be saved is the compute behind the last
+            message (1/8 of the block instead of 1/2).
+        DGNN_DIST_CHUNK_SHAPE=geometric|equal overrides the shape."""
+        remote = f_col[(f_col < self.lo) | (f_col >= self.hi)]
+        halo_rows = int(torch.unique(remote).numel()) if remote.numel() else 0
+        n_remote = max(self.n - self.n_loc, 1)
+        fraction = halo_rows / n_remote
+        wire = halo_rows / max(self.world - 1, 1) / LINK_GBS
+        compute = max(self.nnz_fwd, 1) / GATHER_GBS
+        ratio = wire / compute
+        if not self._solo:
+            dev = self.device if self._nccl() else torch.device("cpu")
+            t = torch.tensor([ratio, -fraction], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            ratio, fraction = float(t[0]), -float(t[1])
+        mode = self.mode
+        if mode == "auto":
+            above = float(os.environ.get("DGNN_DIST_ALLGATHER_ABOVE", "0.9"))
+            mode = "allgather" if (self.world > 1 and fraction >= above) else "halo"
+        wire_bound = ratio > 1.0
+        shape = os.environ.get("DGNN_DIST_CHUNK_SHAPE") or ("equal" if wire_bound else "geometric")
+        if shape not in ("geometric", "equal"):
+            raise ValueError(f"unknown DGNN_DIST_CHUNK_SHAPE {shape!r}")
+        if chunks is None:
+            chunks = 1 if self.world == 1 else 8 if wire_bound else 4
+        chunks = max(1, int(chunks)) if mode == "halo" else 1
+        return {"mode": mode, "chunks": chunks, "chunk_shape": shape, "halo_rows": halo_rows,
+                "halo_fraction_min_over_ranks": round(fraction, 4), "wire_over_compute_max_over_ranks": round(ratio, 3),
+                "link_GBs_assumed": LINK_GBS, "gather_GBs": GATHER_GBS}
+
+    def expected_ms(self, h, f, chunk_overhead_ms=0.1, latency_ms=0.03):
+        """Model of one forward+backward step of THIS rank over real links (bench.py's "expected"
+        key; a prediction to judge the first multi-GPU record against, not a measurement).
+        Per pass the exchanges of the chunks queue on the communicator's stream in chunk order
+        (chunk s: its largest per-peer message / LINK_GBS + a launch latency; messages to different
+        peers use different links), chunk s computes once its rows arrived and chunk s-1 is done
+        (its edges x row bytes / GATHER_GBS + a fixed per-chunk cost: directory pass, merges of cut
+        rows, launches).  The backward's records add 16 bytes per (row, head)."""
+        row = 4.0 * h * f
+        total = 0.0
+        detail = {}
+        for name, extra in (("forward", 4.0 * h), ("backward", 16.0 * h)):
+            if self.mode == "halo":
+                side = self.f_side if name == "forward" else self.b_side
+                msgs = [max(hl.recv_counts + hl.send_counts + [0]) * (row + extra) for hl in side.halos]
+                edges = [blk[3].numel() for blk in side.blocks]
+            else:
+                biggest = max(self.bounds[q + 1] - self.bounds[q] for q in range(self.world))
+                msgs = [biggest * (row + extra)]          # every peer's whole block, one link each
+                edges = [self.nnz_fwd if name == "forward" else self.nnz_bwd]
+            t_wire = t_comp = wire_total = 0.0
+            for m, e in zip(msgs, edges):
+                w = (m / (LINK_GBS * 1e6) + latency_ms) if (self.world > 1 and m > 0) else 0.0
+                t_wire += w
+                wire_total += w
+                t_comp = max(t_comp, t_wire) + e * row / (GATHER_GBS * 1e6) + chunk_overhead_ms
+            total += t_comp
+            detail[name] = {"ms": round(t_comp, 3), "wire_ms": round(wire_total, 3),
+                            "compute_ms": round(sum(edges) * row / (GATHER_GBS * 1e6) + chunk_overhead_ms * len(edges), 3)}
+        return {"ms_per_step": round(total, 3), **detail,
+                "model": (f"per pass: chunk exchanges queue in order at {LINK_GBS:g} GB/s per link (assumed; largest "
+                          f"per-peer message of a chunk) + {latency_ms * 1e3:g} us each, a chunk computes when its rows are "
+                          f"in and the previous chunk is done, at {GATHER_GBS:g} GB/s of gathered rows (measured on one "
+                          f"GPU) + {chunk_overhead_ms:g} ms per chunk; this rank's share, ranks are cost-balanced"),
+                "plan": self.plan}
 
     # ------------------------------------------------------------------ collectives
     def _nccl(self):

@@ -46,6 +46,11 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         from util import LITERAL_TALLY
         for k, v in LITERAL_TALLY.items():      # the reference's own float32 arithmetic on the same inputs
             rows[k]["literal_f32_worst_err_over_plain_tol"] = round(v, 3)
+        from util import LITERAL_RMS
+        for k, (a2, l2, cnt) in LITERAL_RMS.items():
+            if cnt:
+                rows[k]["rms_err_in_ulp_of_mass"] = round((a2 / cnt) ** 0.5, 4)
+                rows[k]["literal_f32_rms_err_in_ulp_of_mass"] = round((l2 / cnt) ** 0.5, 4)
     except Exception:  # pragma: no cover
         pass
     leaning = {k: v for k, v in rows.items() if v["outside_plain_band"]}

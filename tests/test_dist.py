@@ -27,9 +27,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(world, mode, spec, h, f, exchange="halo", chunks=None):
+def run_world(world, mode, spec, h, f, exchange="halo", chunks=None, extra_env=None):
     port = free_port()
-    env = dict(os.environ, DGNN_DIST_MODE=exchange)
+    env = dict(os.environ, DGNN_DIST_MODE=exchange, **(extra_env or {}))
+    env.pop("DGNN_DIST_CHUNKS", None)
     if chunks is not None:
         env["DGNN_DIST_CHUNKS"] = str(chunks)
     with tempfile.TemporaryDirectory() as out_dir:
@@ -104,6 +105,43 @@ def test_partitioned_gat_cpu_gloo_ranks_agree_on_the_pair(world, h):
     spec, f = (10, 700, 6000, 5), 8
     check(run_world(world, "cpunegmix", spec, h, f, "halo", 4), spec, h, f)
     check(run_world(world, "cpuneg", spec, h, f, "halo", 4), spec, h, f)
+
+
+@pytest.mark.parametrize("world,extra", [(2, {}), (3, {}), (2, {"DGNN_DIST_ALLGATHER_ABOVE": "0.2"}),
+                                         (3, {"DGNN_DIST_LINK_GBS": "100000"})])
+def test_partitioned_gat_cpu_gloo_auto_plan(world, extra):
+    """DGNN_DIST_MODE=auto (the default): every rank derives the same plan from the group-wide wire /
+    compute ratio and halo fraction (PartitionedGAT._plan) -- wire-bound: 8 equal chunks; a fast
+    assumed link: 4 geometric chunks; a low all-gather threshold: the all-gather exchange.  Results
+    do not depend on the plan; a rank choosing alone would hang the group (120 s timeout)."""
+    spec, h, f = (10, 700, 6000, 5), 2, 8
+    check(run_world(world, "cpuneg", spec, h, f, "auto", None, extra), spec, h, f)
+
+
+def test_exchange_plan_and_expected_step_model():
+    import torch
+    import dist_worker
+    from dgnn_amd.dist import PartitionedGAT, chunk_fractions
+    assert chunk_fractions(8, "equal") == [0.125] * 8 and chunk_fractions(1, "equal") == [1.0]
+    g = rmat_graph(10, 700, 6000, 5)
+    G = {k: torch.from_numpy(g[k]) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
+    plans = {}
+    for world in (1, 2, 8):
+        r = PartitionedGAT(G, world, 0, torch.device("cpu"), ops=dist_worker.OracleOps(), fake_peers=True)
+        plans[world] = r.plan
+        e = r.expected_ms(4, 64)
+        assert e["ms_per_step"] > 0 and abs(e["forward"]["ms"] + e["backward"]["ms"] - e["ms_per_step"]) < 2e-3
+        assert e["forward"]["ms"] >= max(e["forward"]["compute_ms"] - 1e-3, 0) and e["plan"] is r.plan
+        if world == 1:
+            assert e["forward"]["wire_ms"] == 0 and r.plan["chunks"] == 1
+    # this small graph's halo is large against its edges: wire-bound -> equal chunks
+    assert plans[2]["mode"] == "halo" and plans[2]["chunk_shape"] == "equal" and plans[2]["chunks"] == 8
+    assert 0 < plans[8]["halo_fraction_min_over_ranks"] <= 1
+    # explicit arguments win over the plan
+    r = PartitionedGAT(G, 2, 0, torch.device("cpu"), ops=dist_worker.OracleOps(), fake_peers=True, mode="allgather")
+    assert r.mode == "allgather" and r.chunks == 1 and r.expected_ms(4, 64)["ms_per_step"] > 0
+    r = PartitionedGAT(G, 2, 0, torch.device("cpu"), ops=dist_worker.OracleOps(), fake_peers=True, chunks=3)
+    assert r.chunks == 3 and len(r.f_side.blocks) == 3
 
 
 def test_chunk_fractions_and_incremental_tables():

@@ -651,11 +651,12 @@ def test_gmm(nat, name, k, d, f):
                  literal=oracle.mhsddmm(g["row_ptr"], g["col_ind"], grad, node_feat))
 
 
+@pytest.mark.parametrize("name", ["powerlaw256", "rmat4k"])
 @pytest.mark.parametrize("f", [16, 41, 7])
-def test_gmm_autograd_operator(nat, f, pad_rows):
+def test_gmm_autograd_operator(nat, name, f, pad_rows):
     """Widths that are not multiples of four run zero-padded inside the operator (_pad.py)."""
     from dgnn_amd.operators import GmmConvFuse
-    g = GRAPHS["powerlaw256"]
+    g = GRAPHS[name]
     G = gdev(g)
     k, d = 3, 2
     rng = np.random.default_rng(4)
@@ -1429,4 +1430,4 @@ def test_zz_hip_error_within_twice_the_reference_arithmetic():
     1e-5 / abs 1e-6 tolerance, may not exceed max(1, 2 x the literal's worst).  Runs last in this
     file; vacuous when the labelled tests were deselected."""
     table = assert_within_reference_arithmetic()
-    print("HIP worst / literal float32 worst (x plain tolerance):", table)
+    print("(HIP, literal float32) per label:", table)

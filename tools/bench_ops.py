@@ -101,7 +101,7 @@ def shapes(workload="products"):
     """Fused GAT forward / backward over head x feature shapes other than the headline 4 x 64:
     output layers (1 head x n_classes) and odd widths."""
     from dgnn_amd.native import fused_gatconv as fg
-    g = bench.build_graph(workload, dev)
+    g = bench.build_graph(workload, dev, labels=os.environ.get("DGNN_BENCH_LABELS", "natural"))
     n, nnz = g["n"], g["nnz"]
     gen = torch.Generator(device=dev); gen.manual_seed(0)
     todo = SHAPES           # DGNN_BENCH_SHAPES="1x44,1x48": another list

@@ -7,6 +7,8 @@ cd "$(dirname "$0")/../dgnn_amd/csrc"
 mkdir -p ../../tools/bin
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable \
   -ffp-contract=fast -fno-fast-math -DDGNN_PHASE_CLOCK -c gather.hip -o /tmp/gather_clk.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable \
+  -ffp-contract=fast -fno-fast-math -DDGNN_PHASE_CLOCK -c gather_bwd.hip -o /tmp/gather_bwd_clk.o
 make ops.o convert.o knn.o layer.o >/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/libdgnn_hip_clk.so /tmp/gather_clk.o ops.o convert.o knn.o layer.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/libdgnn_hip_clk.so /tmp/gather_clk.o /tmp/gather_bwd_clk.o ops.o convert.o knn.o layer.o
 echo built tools/bin/libdgnn_hip_clk.so
