@@ -554,6 +554,8 @@ def main():
     ap.add_argument("--simulate-rank", default=None, metavar="R/N",
                     help="time rank R of an N-rank partition ALONE on this GPU, exchanges replaced by local "
                          "copies of the same size (everything but the wire; results are not meaningful)")
+    ap.add_argument("--graph", action="store_true",
+                    help="with --simulate-rank / --force-dist: capture the partitioned step in a HIP graph and replay it")
     ap.add_argument("--no-other-labels", action="store_true",
                     help="skip the extra steps on the other node labelling (profiling runs: one labelling per trace)")
     ap.add_argument("--path", default="operator", choices=["operator", "reference-signature"],
@@ -652,6 +654,23 @@ def main():
         def step_fn():
             runner.forward(x_loc, ar_loc, ac_loc, SLOPE)
             return runner.backward(g_loc)
+
+        if args.graph:
+            # the whole partitioned step as ONE HIP graph (shapes and buffers are fixed between steps): what is left
+            # when the host issues nothing per step.  Rehearsal runs only (--simulate-rank / --force-dist): RCCL
+            # collectives under capture are untested on this pool.
+            if use_pg:
+                raise SystemExit("--graph: rehearsal runs only (--simulate-rank / --force-dist)")
+            eager_step = step_fn
+            for _ in range(3):
+                eager_step()
+            torch.cuda.synchronize()
+            hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hip_graph):
+                eager_step()
+
+            def step_fn():
+                hip_graph.replay()
     else:
         x = in_feat.requires_grad_()
         ar = attn_row.requires_grad_()
@@ -678,6 +697,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step_fn()
+    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3     # host time to issue a step (before the GPU is waited for)
     sync()
     dt = time.perf_counter() - t0
     # peak device memory over the warm-up and timed steps, inputs and graph resident (the reference
@@ -785,7 +805,7 @@ def main():
                         if use_pg else None),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "peak_mem_MB": peak_mem_mb,
+            "data": "synthetic", "peak_mem_MB": peak_mem_mb, "host_enqueue_ms_per_step": round(enqueue_ms, 3),
             "host": {"cpu": cpu_model(), "torch_threads": TORCH_THREADS, "cpu_count": os.cpu_count()},
             "config": {"workload": f"{args.workload}-shaped R-MAT, n={n}, nnz={nnz}, heads={H}, feat={F}, "
                                    f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd, node labels {args.labels}"

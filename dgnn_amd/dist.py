@@ -129,12 +129,16 @@ def chunk_fractions(chunks, shape="geometric"):
 
 
 # The two rates the exchange plan and bench.py's "expected" curve are priced with.
-# LINK: what one xGMI link delivers to an all-to-all message in one direction (153 GB/s peak per link,
-# MI355X_MICROARCH.md; ~2/3 of it assumed achievable by RCCL's point-to-point sends) -- an ASSUMPTION until
-# the first multi-GPU record exists.  GATHER: the rate at which one rank's kernels consume gathered rows,
-# measured on one GPU (products shape: 62 M edges x 1 KiB x 2 passes in 21.9 ms).
-LINK_GBS = float(os.environ.get("DGNN_DIST_LINK_GBS", "100"))
+# LINK: what one xGMI link delivers to an all-to-all message in ONE direction: 153.6 GB/s per link is the
+# two-way figure, 76.8 GB/s each way; 64 GB/s (5/6 of it) is assumed for RCCL's point-to-point sends -- an
+# ASSUMPTION until the first multi-GPU record exists.  GATHER: the rate at which one rank's kernels consume
+# gathered rows, measured on one GPU (products shape: 62 M edges x 1 KiB x 2 passes in 21.9 ms).
+# WIRE_BOUND_ABOVE: wire / compute ratio from which the equal-chunk pipeline is planned; between the products
+# shape on 8 ranks (1.26: 4 geometric chunks model best) and on 4 ranks (1.62: 8 equal chunks model best),
+# profiles/r3k_dist_plan_model.jsonl.
+LINK_GBS = float(os.environ.get("DGNN_DIST_LINK_GBS", "64"))
 GATHER_GBS = float(os.environ.get("DGNN_DIST_GATHER_GBS", "5800"))
+WIRE_BOUND_ABOVE = float(os.environ.get("DGNN_DIST_WIRE_BOUND_ABOVE", "1.4"))
 
 
 class _NoWait:
@@ -316,12 +320,13 @@ class PartitionedGAT:
           * DGNN_DIST_MODE=auto (default): "allgather" when every rank references >=
             DGNN_DIST_ALLGATHER_ABOVE (0.9) of the remote rows -- the halo lists, packs and
             relabelled tables then buy nothing over two plain all-gathers; "halo" otherwise.
-          * chunks (when neither the argument nor DGNN_DIST_CHUNKS fixes them): compute-bound
-            (ratio <= 1, e.g. products on 8 or 4 ranks) -> 4 geometric chunks, the small first
-            chunk bounds the exposed exchange; wire-bound (ratio > 1, e.g. products on 2 ranks:
-            56 % of the other half over ONE link) -> 8 equal chunks, the exchange is the critical
-            path from the first byte and what can still be saved is the compute behind the last
-            message (1/8 of the block instead of 1/2).
+          * chunks (when neither the argument nor DGNN_DIST_CHUNKS fixes them): ratio <=
+            WIRE_BOUND_ABOVE (products on 8 ranks: 1.26) -> 4 geometric chunks, the small first
+            chunk bounds the exposed exchange; above it (products on 4 ranks: 1.62; on 2 ranks,
+            56 % of the other half over ONE link: 2.0) -> 8 equal chunks, the exchange is the
+            critical path from the first byte and what can still be saved is the compute behind
+            the last message (1/8 of the block instead of 1/2).  The model's own comparison of
+            the candidates: profiles/r3k_dist_plan_model.jsonl.
         DGNN_DIST_CHUNK_SHAPE=geometric|equal overrides the shape."""
         remote = f_col[(f_col < self.lo) | (f_col >= self.hi)]
         halo_rows = int(torch.unique(remote).numel()) if remote.numel() else 0
@@ -339,7 +344,7 @@ class PartitionedGAT:
         if mode == "auto":
             above = float(os.environ.get("DGNN_DIST_ALLGATHER_ABOVE", "0.9"))
             mode = "allgather" if (self.world > 1 and fraction >= above) else "halo"
-        wire_bound = ratio > 1.0
+        wire_bound = ratio > WIRE_BOUND_ABOVE
         shape = os.environ.get("DGNN_DIST_CHUNK_SHAPE") or ("equal" if wire_bound else "geometric")
         if shape not in ("geometric", "equal"):
             raise ValueError(f"unknown DGNN_DIST_CHUNK_SHAPE {shape!r}")
