@@ -297,8 +297,11 @@ def bench_gmm(args, device):
     roof = None
     if kms > 0:
         ach = nbytes / (kms * 1e-3) / 1e9
+        inst = (name or "").split("dgnn::")[-1].split("(")[0]        # "k_bwd_col_gather<4, 2, 4, 1, true, 0>"
+        traffic, traffic_src = measured_traffic(args.workload, inst)
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": name, "kernel_instance": name, "algorithmic_bytes": nbytes, "kernel_ms": round(kms, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_from_profile": True,
+                "kernel": name, "kernel_instance": name, "algorithmic_bytes": nbytes, "kernel_ms": round(kms, 4),
                 "fwd_kernel_ms": round(kf, 4), "bwd_kernel_ms": round(kb, 4),
                 "survey_reference_3kernel_backward_bytes": b_survey}
         if n * K * F * 4 <= 256 << 20:

@@ -513,7 +513,9 @@ def test_gat_linearity_and_row_stochasticity_at_scale(nat):
         sub_ptr[i + 1] = sub_ptr[i] + seg.size
     sub_col = np.concatenate(cols).astype(np.int32)
     o64, _, _ = oracle.gat_forward_f64(host(ar)[rows], host(ac), sub_ptr, sub_col, 0.2, host(x), 0.0, None)
-    assert_close(host(ox)[rows], o64, "sampled rows vs oracle", atol=2e-6)
+    # summand mass of a sampled row: the same softmax-weighted sum over |x|
+    m64, _, _ = oracle.gat_forward_f64(host(ar)[rows], host(ac), sub_ptr, sub_col, 0.2, np.abs(host(x)), 0.0, None)
+    assert_close(host(ox)[rows], o64, "sampled rows vs oracle", mass=m64)
 
 
 @pytest.mark.parametrize("name", SPMM_GRAPHS)
@@ -1054,8 +1056,16 @@ def test_gat_autograd_operator_on_a_rectangular_block_with_odd_width(nat, m, n, 
     ref.backward(torch.tensor(go_np, dtype=torch.float64))
     assert_close(host(out), ref.detach().numpy(), "rectangular odd width: out")
     assert_close(host(x.grad), X.grad.numpy(), "rectangular odd width: grad_feat")
-    assert_close(host(ar.grad), AR.grad.numpy(), "rectangular odd width: grad_attn_row", atol=2e-6)
-    assert_close(host(ac.grad), AC.grad.numpy(), "rectangular odd width: grad_attn_col", atol=2e-6)
+    # summand masses of the two score gradients (tests/util.py::gat_masses, rectangular): every edge contributes
+    # a (|g| + |S|) with |g| = sum_f |grad||x|, |S| = sum_j a_j |g_j|
+    with torch.no_grad():
+        a_, gx = a.detach(), (torch.tensor(go_np, dtype=torch.float64).abs()[row] * X.detach().abs()[col]).sum(-1)
+        s_abs = torch.zeros((m, h), dtype=torch.float64).index_add(0, row, a_ * gx)
+        me = a_ * (gx + s_abs[row])
+        m_gr = torch.zeros((m, h), dtype=torch.float64).index_add(0, row, me).numpy()
+        m_gc = torch.zeros((n, h), dtype=torch.float64).index_add(0, col, me).numpy()
+    assert_close(host(ar.grad), AR.grad.numpy(), "rectangular odd width: grad_attn_row", mass=m_gr)
+    assert_close(host(ac.grad), AC.grad.numpy(), "rectangular odd width: grad_attn_col", mass=m_gc)
 
 
 @pytest.mark.parametrize("h,f", [(2, 16), (3, 41), (1, 7)])
