@@ -1038,7 +1038,7 @@ PYBIND11_MODULE(fused_gatconv, m) {
       arg("a_neg") = py::none());
   def(m, "gat_backward", &gat_backward,
       "negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum, edge_mask, "
-      "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None",
+      "in_feat, attn_row, attn_col, grad, out_feat=None, row_dot=None, out=None, out_neg=None, a_neg=None",
       "-> [grad_feat, grad_attn_row, grad_attn_col]   (fused_gatconv.cpp:104-166).  out_feat / row_dot (keywords,\n"
       "not in the reference signature) remove one whole gather pass from the backward.  out = (grad_feat,\n"
       "grad_attn_row, grad_attn_col), entries may be None: write into these tensors instead of new ones.",

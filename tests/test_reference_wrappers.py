@@ -43,13 +43,17 @@ def _bound(native_mod_name, fn_name, impl):
 
 @pytest.fixture()
 def ref_ops(monkeypatch):
-    def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask, out):
+    def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop, edge_mask, out, neg, saved):
+        # the reference's wrapper passes seven arguments: the keywords keep their defaults (neg=False, saved=True: on
+        # the GPU the fourth result then carries the forward state, tests/test_gpu_parity.py); the oracle-backed
+        # stand-in returns the empty mask of attn_drop == 0
+        assert edge_mask is None and out is None and neg is False and saved is True
         out, emax, esum = oracle.gat_forward(N(attn_row), N(attn_col), N(row_ptr), N(col_ind), negative_slope,
                                              N(in_feat), attn_drop, None)
         return [T(out), T(emax), T(esum), torch.empty((0, attn_row.size(1)))]
 
     def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
-                     edge_mask, in_feat, attn_row, attn_col, grad, out_feat, row_dot, out):
+                     edge_mask, in_feat, attn_row, attn_col, grad, out_feat, row_dot, out, out_neg=None, a_neg=None):
         gf, gr, gc = oracle.gat_backward(negative_slope, attn_drop, N(row_ptr), N(col_ind), N(col_ptr), N(row_ind),
                                          N(permute), N(edge_max), N(edge_sum), None, N(in_feat), N(attn_row),
                                          N(attn_col), N(grad))
