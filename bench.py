@@ -42,6 +42,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # measured single-GPU steps (scrambled labels, profiles/r3h_bench_line_products.json, r3i_bench_line_reddit.json):
 # the denominator of the "expected" multi-GPU curve
 SINGLE_GPU_MS = {"products": 21.85, "reddit": 29.4}
+# one rank's head-parallel step timed ALONE on one GPU (bench.py --simulate-rank R/N; nothing is exchanged in that
+# split but one small all-reduce at 8 ranks, so this is a rank's step time): profiles/r3p_dist_head_parallel_ranks.jsonl
+RANK_ALONE_MS = {"products": {2: 11.68, 4: 6.61, 8: 4.24}}
 # collectives of a bench run take milliseconds: a rank that waits this long has lost a peer
 TORCH_THREADS = torch.get_num_threads()     # (read at start-up: loading the OpenMP oracle later changes what torch reports)
 PG_TIMEOUT = __import__("datetime").timedelta(seconds=int(os.environ.get("DGNN_PG_TIMEOUT", "120")))
@@ -557,6 +560,9 @@ def main():
     ap.add_argument("--simulate-rank", default=None, metavar="R/N",
                     help="time rank R of an N-rank partition ALONE on this GPU, exchanges replaced by local "
                          "copies of the same size (everything but the wire; results are not meaningful)")
+    ap.add_argument("--strategy", default=None, choices=["auto", "heads", "rows"],
+                    help="multi-GPU: heads = every rank runs the whole graph on heads/N heads, no exchange (needs heads %% N "
+                         "== 0); rows = row partition with halo exchange; auto (default, or DGNN_DIST_STRATEGY): heads when possible")
     ap.add_argument("--graph", action="store_true",
                     help="with --simulate-rank / --force-dist: capture the partitioned step in a HIP graph and replay it")
     ap.add_argument("--no-other-labels", action="store_true",
@@ -638,20 +644,33 @@ def main():
     grad_out = (torch.rand((n, H, F), device=device, generator=gen) - 0.5)
 
     if use_pg or args.force_dist or args.simulate_rank:
-        from dgnn_amd.dist import PartitionedGAT
+        # head split (no exchange) when the heads divide by the ranks, row partition + halo exchange otherwise
+        # (dgnn_amd.dist.make_gat_runner; --strategy / DGNN_DIST_STRATEGY overrides)
+        from dgnn_amd.dist import make_gat_runner
         if args.simulate_rank:
             sim_r, sim_n = (int(v) for v in args.simulate_rank.split("/"))
-            runner = PartitionedGAT(g, sim_n, sim_r, device, fake_peers=True)    # chunks: DGNN_DIST_CHUNKS or the plan's
+            runner = make_gat_runner(g, sim_n, sim_r, device, H, feat=F, strategy=args.strategy,
+                                     fake_peers=True)    # chunks: DGNN_DIST_CHUNKS or the plan's
         else:
-            runner = PartitionedGAT(g, world, rank, device)
+            runner = make_gat_runner(g, world, rank, device, H, feat=F, strategy=args.strategy)
         lo, hi = runner.lo, runner.hi
         # the rank's inputs live where the operator gathers from (as the GEMM in front of the
         # operator / autograd behind it would produce them): no copy of local rows inside a step
-        x_loc = runner.input_buffer("forward", (H, F))
-        x_loc.copy_(in_feat[lo:hi])
-        g_loc = runner.input_buffer("backward", (H, F))
-        g_loc.copy_(grad_out[lo:hi])
-        ar_loc, ac_loc = attn_row[lo:hi].contiguous(), attn_col[lo:hi].contiguous()
+        if runner.mode == "heads":          # [lo, hi) is this rank's head range (and a feature slice beyond one head per rank)
+            H_loc = hi - lo
+            F_loc = F if runner.f_lo is None else runner.f_hi - runner.f_lo
+            x_loc = runner.input_buffer("forward", (H_loc, F_loc))
+            x_loc.copy_(runner.local(in_feat))
+            g_loc = runner.input_buffer("backward", (H_loc, F_loc))
+            g_loc.copy_(runner.local(grad_out))
+            ar_loc, ac_loc = runner.local_scores(attn_row), runner.local_scores(attn_col)
+        else:
+            H_loc, F_loc = H, F
+            x_loc = runner.input_buffer("forward", (H, F))
+            x_loc.copy_(in_feat[lo:hi])
+            g_loc = runner.input_buffer("backward", (H, F))
+            g_loc.copy_(grad_out[lo:hi])
+            ar_loc, ac_loc = attn_row[lo:hi].contiguous(), attn_col[lo:hi].contiguous()
         del in_feat, grad_out
 
         def step_fn():
@@ -789,15 +808,17 @@ def main():
         if kf > 0 and kb > 0:
             # the kernels timed are those of the LAST (largest) chunk of rank 0's block
             (rows_f, nnz_f), (cols_b, nnz_b) = runner.last_fwd, runner.last_bwd
-            bf = algorithmic_bytes(rows_f, nnz_f, H, F)["fwd"]
-            bb = algorithmic_bytes(cols_b, nnz_b, H, F)["bwd_csc"]
+            bf = algorithmic_bytes(rows_f, nnz_f, H_loc, F_loc)["fwd"]
+            bb = algorithmic_bytes(cols_b, nnz_b, H_loc, F_loc)["bwd_csc"]
             name, nbytes, ms = ("k_bwd_col_gather", bb, kb) if kb >= kf else ("k_fast_row_gather", bf, kf)
             achieved = nbytes / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": f"{name} on the last of {runner.chunks} chunk(s) of rank 0's block ({rows_f} rows x "
-                              f"{nnz_f} edges forward, {cols_b} columns x {nnz_b} edges backward; the block: "
-                              f"{runner.n_loc} nodes, {runner.nnz_fwd} / {runner.nnz_bwd} edges)",
+                    "kernel": (f"{name} on rank 0's slice ({H_loc} of {H} heads x {F_loc} of {F} features) of the whole graph"
+                               if runner.mode == "heads" else
+                               f"{name} on the last of {runner.chunks} chunk(s) of rank 0's block ({rows_f} rows x "
+                               f"{nnz_f} edges forward, {cols_b} columns x {nnz_b} edges backward; the block: "
+                               f"{runner.n_loc} nodes, {runner.nnz_fwd} / {runner.nnz_bwd} edges)"),
                     "algorithmic_bytes": nbytes, "kernel_ms": round(ms, 3),
                     "fwd_kernel_ms": round(kf, 3), "bwd_kernel_ms": round(kb, 3)}
     if rank == 0:
@@ -814,23 +835,39 @@ def main():
                                    f"attn_drop={args.attn_drop:g}, fused GATConvFuse fwd+bwd, node labels {args.labels}"
                                    + (" (load-time relabelling, dgnn_amd.graph.relabel_nodes)" if args.labels == "scrambled" else ""),
                        "parallelism": "single GPU" if world == 1 else
-                       f"row-partition x{world}, RCCL {os.environ.get('DGNN_DIST_MODE', 'halo')} exchange of boundary rows"
-                       + (f", {runner.chunks} pipelined chunks" if runner.mode == "halo" else "")},
+                       (f"head-parallel x{world}: every rank runs the whole graph on {H_loc} of the {H} heads"
+                        + (f" x {F_loc} of the {F} features" if F_loc != F else "") + f"; exchange: {runner.plan['exchange']}"
+                        if runner.mode == "heads" else
+                        f"row-partition x{world}, RCCL {runner.mode} exchange of boundary rows"
+                        + (f", {runner.chunks} pipelined chunks" if runner.mode == "halo" else ""))},
         }
         if roof is not None:
             line["roofline"] = roof
         if use_pg or args.force_dist or args.simulate_rank:
             # a PREDICTION of this step over real links (dgnn_amd.dist.PartitionedGAT.expected_ms): the curve a
             # multi-GPU record is to be judged against; speedup against the measured single-GPU step
-            exp = runner.expected_ms(H, F)
+            exp = runner.expected_ms(H_loc, F_loc)
             exp["single_gpu_ms_per_step"] = SINGLE_GPU_MS.get(args.workload)
+            n_ranks = sim_n if args.simulate_rank else world
+            alone = RANK_ALONE_MS.get(args.workload, {}).get(n_ranks) if (runner.mode == "heads" and (H, F) == (4, 64)) else None
+            if alone:        # measured beats modelled: the narrow slices run below the wide rows' gather rate
+                exp["model_ms_per_step"] = exp["ms_per_step"]
+                exp["rank_alone_ms_per_step_measured"] = alone
+                exp["ms_per_step"] = round(alone + exp.get("all_reduce_ms", 0.0), 3)
             if exp["single_gpu_ms_per_step"]:
                 exp["speedup_over_one_gpu"] = round(exp["single_gpu_ms_per_step"] / exp["ms_per_step"], 2)
             line["expected"] = exp
         if args.simulate_rank:
-            line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
-                                 f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")
-            line["value"] = runner.nnz_fwd / (ms_per_step * 1e-3)
+            if runner.mode == "heads":
+                line["simulated"] = (f"rank {sim_r} of {sim_n} alone on its slice ({H_loc} of {H} heads x {F_loc} of {F} features; "
+                                     f"head-parallel: no rows are exchanged, so this IS a rank's step time"
+                                     + ("" if runner.q == 1 else " up to one small all-reduce")
+                                     + "): value = its share of the work / time, NOT a multi-GPU result")
+                line["value"] = nnz * (H_loc * F_loc) / (H * F) / (ms_per_step * 1e-3)
+            else:
+                line["simulated"] = (f"rank {sim_r} of {sim_n} alone, exchanges as local copies: "
+                                     f"value = this rank's {runner.nnz_fwd} edges / time, NOT a multi-GPU result")
+                line["value"] = runner.nnz_fwd / (ms_per_step * 1e-3)
         if world == 1 and not use_pg and not args.force_dist and not args.simulate_rank:
             # the same steps through the other calling convention (INTEGRATION.md option A / the operator)
             line["config"]["path"] = args.path

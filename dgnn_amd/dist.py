@@ -747,6 +747,149 @@ class PartitionedGAT:
 
 
 # ----------------------------------------------------------------------------------------------
+# Head-parallel GAT: the other way to put the operator on several GPUs.  Heads never interact inside
+# the fused operator -- softmax and aggregation run per (row, head), fused_gatconv_kernel.cu:32-35,
+# and so do all three gradients -- so rank p can run the WHOLE graph on heads [p H/P, (p+1) H/P) of
+# in_feat / attn_row / attn_col / grad with NO exchange at all: no halo, no index lists, perfect
+# balance whatever the graph looks like.  With more ranks than heads (P = q H) a head's FEATURES are
+# cut into q slices as well: out and grad_feat are independent per feature given the scores, and the
+# two score gradients are linear in <grad, in_feat> and <grad, out>, so every rank of a head computes
+# them from its partial dot products and ONE all-reduce of [N, 2] floats per head group (10 MB at the
+# products shape, against 0.75 GB of halo rows per pass) sums them.  The price is paid outside the
+# operator (the layer's projection becomes column-parallel: every rank needs the layer input, i.e.
+# tensor parallelism) and in row width: a rank's rows are P times narrower than the single-GPU rows,
+# so the per-rank kernels are the narrow-row ones.
+#
+# Which one: on the products shape the row partition moves 35-56 % of the remote rows per pass and
+# is predicted to LOSE at two ranks (one xGMI link), while one rank's step on
+# 2 x 64 / 1 x 64 / 1 x 32 slices takes 11.7 / 6.6 / 4.3 ms against 21.85 ms on one GPU -- the last
+# equal to what a rank of the 8-way row partition computes BEFORE its exchange.  make_gat_runner()
+# therefore picks the slice split whenever heads and features divide and the row partition
+# otherwise; DGNN_DIST_STRATEGY=rows|heads overrides.  The choice depends on (heads, features, world)
+# alone, so every rank makes it without talking to the others.
+def slice_layout(heads, world, feat=None):
+    """(heads per rank, feature slices per head) of the head-parallel split, or None when (heads, feat) do not
+    divide over ``world`` ranks: whole heads when heads % world == 0, else world = q * heads with q slices
+    of feat / q >= 4 floats per head."""
+    if heads % world == 0:
+        return heads // world, 1
+    if world % heads == 0 and feat is not None:
+        q = world // heads
+        if feat % q == 0 and feat // q >= 4:
+            return 1, q
+    return None
+
+
+class HeadParallelGAT:
+    """Fused GAT forward+backward on rank ``rank``'s heads (and, with more ranks than heads, its feature
+    slice of one head) of the whole graph.  Same calling convention as PartitionedGAT, with ``local()`` /
+    ``local_scores()`` cutting full [N,H,F] / [N,H] tensors to this rank's part; ``lo`` / ``hi`` are the
+    head range, ``f_lo`` / ``f_hi`` the feature range (None = all)."""
+
+    mode = "heads"
+
+    def __init__(self, graph, world, rank, device, heads, feat=None, ops=None, group=None, fake_peers=False):
+        lay = slice_layout(heads, world, feat)
+        if lay is None:
+            raise ValueError(f"head-parallel GAT: heads={heads}, feat={feat} do not divide over {world} ranks")
+        self.world, self.rank, self.device, self.heads = world, rank, device, heads
+        self.h_local, self.q = lay
+        if self.q == 1:
+            self.lo, self.hi = rank * self.h_local, (rank + 1) * self.h_local
+            self.f_lo = self.f_hi = None
+        else:
+            self.lo, self.hi = rank // self.q, rank // self.q + 1
+            fq = feat // self.q
+            self.f_lo, self.f_hi = (rank % self.q) * fq, (rank % self.q + 1) * fq
+        # the ranks that share my head sum their partial score gradients; every rank creates every group,
+        # in the same order (torch.distributed's rule)
+        self._group = None
+        if self.q > 1 and not fake_peers and dist.is_initialized() and dist.get_world_size(group) > 1:
+            for hh in range(heads):
+                grp = dist.new_group([hh * self.q + j for j in range(self.q)])
+                if hh == self.lo:
+                    self._group = grp
+        # one rank's worth of the row-partitioned runner on the whole graph: the same kernels in the same
+        # order as the single-GPU operator (pair forward, one row pass, one column-gather pass), its
+        # persistent input buffers, and no collective (fake_peers: nothing is ever exchanged)
+        self._inner = PartitionedGAT(graph, 1, 0, device, ops=ops, mode="halo", chunks=1, fake_peers=True)
+        self.n, self.n_loc = self._inner.n, self._inner.n
+        self.nnz_fwd, self.nnz_bwd = self._inner.nnz_fwd, self._inner.nnz_bwd
+        self.chunks = 1
+        self.last_fwd, self.last_bwd = self._inner.last_fwd, self._inner.last_bwd
+        self.plan = {"mode": "heads", "heads_per_rank": self.h_local, "feature_slices_per_head": self.q,
+                     "exchange": "none" if self.q == 1 else
+                     f"one all-reduce of [N, 2] floats over the {self.q} ranks of a head per step",
+                     "gather_GBs": GATHER_GBS, "link_GBs_assumed": LINK_GBS}
+
+    def local(self, t):
+        """This rank's heads (and feature slice) of a full [N, H, F] tensor."""
+        t = t[:, self.lo:self.hi]
+        return (t if self.f_lo is None else t[:, :, self.f_lo:self.f_hi]).contiguous()
+
+    def local_scores(self, t):
+        """This rank's heads of a full [N, H] tensor (attn_row / attn_col: whole on every rank of a head)."""
+        return t[:, self.lo:self.hi].contiguous()
+
+    def input_buffer(self, which, tail_shape, dtype=torch.float32):
+        return self._inner.input_buffer(which, tail_shape, dtype)
+
+    def forward(self, in_feat_loc, attn_row_loc, attn_col_loc, slope):
+        """[N, heads per rank, feature slice] of GATConvFuse(...)."""
+        return self._inner.forward(in_feat_loc, attn_row_loc, attn_col_loc, slope)
+
+    def backward(self, grad_out_loc):
+        """-> (grad_feat of this rank's slice, grad_attn_row [N,h], grad_attn_col [N,h] of its heads; with
+        feature slices the last two are summed over the head's ranks and identical on all of them)."""
+        gf, gr, gc = self._inner.backward(grad_out_loc)
+        if self._group is not None:
+            both = torch.cat((gr, gc), dim=1)
+            if both.is_cuda and dist.get_backend(self._group) != "nccl":
+                host = both.cpu()                       # e.g. gloo ranks sharing one card (tests)
+                dist.all_reduce(host, group=self._group)
+                both.copy_(host)
+            else:
+                dist.all_reduce(both, group=self._group)
+            gr, gc = both[:, :gr.size(1)].contiguous(), both[:, gr.size(1):].contiguous()
+        return gf, gr, gc
+
+    def step(self, in_feat, attn_row, attn_col, grad_out, slope):
+        self.forward(self.local(in_feat), self.local_scores(attn_row), self.local_scores(attn_col), slope)
+        return self.backward(self.local(grad_out))
+
+    def expected_ms(self, h, f, chunk_overhead_ms=0.1, latency_ms=0.03):
+        """No halo: the rank's kernels on rows of h x f floats (its slice) at GATHER_GBS -- optimistic for
+        narrow slices, whose kernels run below that rate; bench.py --simulate-rank R/N
+        measures the real figure on one GPU, since no row is exchanged -- plus, with feature slices, the
+        ring all-reduce of [N, 2h] floats over the head's q ranks at LINK_GBS."""
+        e = self._inner.expected_ms(h, f, chunk_overhead_ms, latency_ms)
+        ar_ms = 0.0
+        if self.q > 1:
+            ar_ms = 2.0 * (self.q - 1) / self.q * (8.0 * h * self.n) / (LINK_GBS * 1e6) + 2 * (self.q - 1) * latency_ms
+        e["ms_per_step"] = round(e["ms_per_step"] + ar_ms, 3)
+        e["all_reduce_ms"] = round(ar_ms, 3)
+        e["plan"] = self.plan
+        e["model"] = (f"head-parallel: no rows exchanged; the whole graph on a slice of {h} head(s) x {f} features per rank at "
+                      f"{GATHER_GBS:g} GB/s of gathered rows + {chunk_overhead_ms:g} ms per pass"
+                      + (f" + one ring all-reduce of [N,{2 * h}] floats over {self.q} ranks at {LINK_GBS:g} GB/s (assumed)"
+                         if self.q > 1 else ""))
+        return e
+
+
+def make_gat_runner(graph, world, rank, device, heads, feat=None, ops=None, group=None, strategy=None, **kw):
+    """The multi-GPU runner for a fused GAT of ``heads`` x ``feat``: HeadParallelGAT when heads (and, beyond
+    one head per rank, features) divide over the ranks -- no rows exchanged --, PartitionedGAT (row partition,
+    halo exchange) otherwise.  ``strategy`` / DGNN_DIST_STRATEGY: "auto" (default), "heads", "rows"."""
+    strategy = strategy or os.environ.get("DGNN_DIST_STRATEGY", "auto")
+    if strategy not in ("auto", "heads", "rows"):
+        raise ValueError(f"unknown strategy {strategy!r}")
+    if strategy == "heads" or (strategy == "auto" and world > 1 and slice_layout(heads, world, feat) is not None):
+        return HeadParallelGAT(graph, world, rank, device, heads, feat=feat, ops=ops, group=group,
+                               fake_peers=bool(kw.get("fake_peers", False)))
+    return PartitionedGAT(graph, world, rank, device, ops=ops, group=group, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
 # EdgeConv / DGCNN: data parallel over point clouds (BASELINE.json configs[2]; SURVEY.md 8(e)
 # "replicas only").  The k-NN graph never crosses clouds (script/train/train_edgeconv.py:49), so
 # the fused operators need no exchange at all: every rank runs the single-GPU kernels on its own

@@ -10,6 +10,9 @@ mode "cpunegmix": the pair is missing on rank 1 only: every rank must fall back 
 mode "gpu": gloo backend, every rank on cuda:0, compute through the real HIP kernels.
 mode "nccl": rank r on cuda:r with the nccl (= RCCL) backend: the multi-GPU path as it runs in
             production; needs a GPU per rank (tests skip themselves on a one-GPU box).
+mode "cpuheads" / "gpuheads" / "ncclheads": the head-parallel runner (dgnn_amd.dist.HeadParallelGAT through
+            make_gat_runner): every rank runs the whole graph on its heads, nothing is exchanged; gloo on the CPU
+            (oracle stand-in), gloo with every rank on cuda:0, RCCL with a GPU per rank.
 mode "nccl1": ONE rank on cuda:0 with the nccl (= RCCL) backend and DGNN_DIST_FORCE_COLLECTIVES=1:
             every collective of the step is really issued through RCCL (RCCL wants one GPU per
             rank, so one rank is what a one-GPU box can rehearse).
@@ -155,7 +158,7 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
     if mode == "nccl1":      # one rank, RCCL backend, collectives forced: rehearses the calls on one GPU
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
-    elif mode == "nccl":
+    elif mode in ("nccl", "ncclheads"):
         from datetime import timedelta
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"),
@@ -164,11 +167,35 @@ def run(rank, world, mode, port, out_dir, graph_spec, h, f):
         from datetime import timedelta
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
     from util import gat_inputs, rmat_graph
-    from dgnn_amd.dist import PartitionedGAT
+    from dgnn_amd.dist import PartitionedGAT, make_gat_runner
     g = rmat_graph(*graph_spec)
     in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
-    device = torch.device("cpu" if mode in ("cpu", "cpuneg", "cpunegmix") else f"cuda:{rank}" if mode == "nccl" else "cuda:0")
+    device = torch.device("cpu" if mode in ("cpu", "cpuneg", "cpunegmix", "cpuheads") else
+                          f"cuda:{rank}" if mode in ("nccl", "ncclheads") else "cuda:0")
     G = {k: torch.from_numpy(g[k]).to(device) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
+    if mode.endswith("heads"):
+        # default strategy: the heads divide by the world size, so the factory must pick the head split itself
+        runner = make_gat_runner(G, world, rank, device, h, feat=f, ops=OracleOpsNeg() if mode == "cpuheads" else None)
+        assert runner.mode == "heads" and (runner.hi - runner.lo) * world == h * runner.q
+        t = lambda a: torch.from_numpy(a).to(device)
+        f_loc = f if runner.f_lo is None else runner.f_hi - runner.f_lo
+        x_loc = runner.input_buffer("forward", (runner.hi - runner.lo, f_loc))
+        x_loc.copy_(runner.local(t(in_feat)))
+        out = runner.forward(x_loc, runner.local_scores(t(attn_row)), runner.local_scores(t(attn_col)), 0.2)
+        gf, gr, gc = runner.backward(runner.local(t(grad)))
+        out2 = runner.forward(x_loc, runner.local_scores(t(attn_row)), runner.local_scores(t(attn_col)), 0.2)
+        gf2, gr2, gc2 = runner.backward(runner.local(t(grad)))
+        for u, v in ((out, out2), (gf, gf2), (gr, gr2), (gc, gc2)):
+            assert torch.equal(u, v), "the second step must repeat the first bit for bit"
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=runner.lo, hi=runner.hi,
+                 f_lo=0 if runner.f_lo is None else runner.f_lo, f_hi=f if runner.f_hi is None else runner.f_hi,
+                 out=out.cpu().numpy(), gf=gf.cpu().numpy(), gr=gr.cpu().numpy(), gc=gc.cpu().numpy(),
+                 nnz_fwd=runner.nnz_fwd, nnz_bwd=runner.nnz_bwd)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     ops = (OracleOps() if mode == "cpu" else OracleOpsNeg() if mode == "cpuneg" else
            OracleOpsNegOnSomeRanks(rank) if mode == "cpunegmix" else None)
     runner = PartitionedGAT(G, world, rank, device, ops=ops)

@@ -144,6 +144,68 @@ def test_exchange_plan_and_expected_step_model():
     assert r.chunks == 3 and len(r.f_side.blocks) == 3
 
 
+def check_heads(parts, spec, h, f):
+    """Head-parallel ranks: every rank holds ALL rows of its head range; the ranges tile [0, h)."""
+    g = rmat_graph(*spec)
+    in_feat, attn_row, attn_col, grad = gat_inputs(g["n"], h, f, seed=21)
+    o64, _, _ = oracle.gat_forward_f64(attn_row, attn_col, g["row_ptr"], g["col_ind"], 0.2, in_feat, 0.0)
+    gf64, gr64, gc64 = oracle.gat_backward_f64(0.2, 0.0, g["row_ptr"], g["col_ind"], None, in_feat,
+                                               attn_row, attn_col, grad)
+    m_out, m_gf, m_gr, m_gc = gat_masses(g, attn_row, attn_col, in_feat, grad, 0.2)
+    assert all(int(p["nnz_fwd"]) == g["nnz"] == int(p["nnz_bwd"]) for p in parts)      # the whole graph on every rank
+    # the slices tile [0, h) x [0, f) exactly once
+    cover = np.zeros((h, f), np.int32)
+    out, gf = np.zeros_like(o64, dtype=np.float32), np.zeros_like(gf64, dtype=np.float32)
+    gr, gc = np.zeros_like(gr64, dtype=np.float32), np.zeros_like(gc64, dtype=np.float32)
+    for p in parts:
+        lo, hi, f_lo, f_hi = int(p["lo"]), int(p["hi"]), int(p["f_lo"]), int(p["f_hi"])
+        cover[lo:hi, f_lo:f_hi] += 1
+        out[:, lo:hi, f_lo:f_hi], gf[:, lo:hi, f_lo:f_hi] = p["out"], p["gf"]
+        if f_lo == 0:
+            gr[:, lo:hi], gc[:, lo:hi] = p["gr"], p["gc"]
+        else:       # the score gradients are summed over a head's ranks: identical on all of them
+            assert np.array_equal(gr[:, lo:hi], p["gr"]) and np.array_equal(gc[:, lo:hi], p["gc"])
+    assert (cover == 1).all()
+    assert_close(out, o64, "head-parallel out_feat", mass=m_out)
+    assert_close(gf, gf64, "head-parallel grad_feat", mass=m_gf)
+    assert_close(gr, gr64, "head-parallel grad_attn_row", mass=m_gr)
+    assert_close(gc, gc64, "head-parallel grad_attn_col", mass=m_gc)
+
+
+@pytest.mark.parametrize("world,h,f", [(2, 4, 8), (4, 4, 8), (2, 2, 8), (3, 6, 8), (8, 4, 16), (4, 2, 8), (2, 1, 12)])
+def test_head_parallel_gat_cpu_gloo(world, h, f):
+    """dgnn_amd.dist.make_gat_runner picks the head split when heads % world == 0 -- every rank runs the whole graph
+    on its heads with no exchange -- and heads x feature slices when world is a multiple of the heads (8 ranks on
+    4 heads: two feature halves per head, the score gradients summed by one all-reduce inside each head's pair).
+    The slices assemble to the single-graph result."""
+    spec = (10, 700, 6000, 5)
+    check_heads(run_world(world, "cpuheads", spec, h, f, "auto"), spec, h, f)
+
+
+def test_runner_factory_picks_heads_or_rows():
+    import torch
+    import dist_worker
+    from dgnn_amd.dist import HeadParallelGAT, PartitionedGAT, make_gat_runner
+    g = rmat_graph(10, 700, 6000, 5)
+    G = {k: torch.from_numpy(g[k]) for k in ("row_ptr", "col_ind", "col_ptr", "row_ind")}
+    mk = lambda world, heads, **kw: make_gat_runner(G, world, 0, torch.device("cpu"), heads, ops=dist_worker.OracleOps(),
+                                                    fake_peers=True, **kw)
+    assert isinstance(mk(2, 4), HeadParallelGAT) and isinstance(mk(4, 4), HeadParallelGAT)
+    assert isinstance(mk(8, 4), PartitionedGAT) and isinstance(mk(3, 4), PartitionedGAT)      # heads do not divide
+    assert isinstance(mk(8, 4, feat=64), HeadParallelGAT) and mk(8, 4, feat=64).q == 2         # ... but 4 x 2 slices do
+    assert isinstance(mk(8, 4, feat=4), PartitionedGAT) and isinstance(mk(8, 4, feat=63), PartitionedGAT)
+    r8 = make_gat_runner(G, 8, 5, torch.device("cpu"), 4, feat=64, ops=dist_worker.OracleOps(), fake_peers=True)
+    assert (r8.lo, r8.hi, r8.f_lo, r8.f_hi) == (2, 3, 32, 64) and r8.expected_ms(1, 32)["all_reduce_ms"] > 0
+    assert isinstance(mk(1, 4), PartitionedGAT)
+    assert isinstance(mk(2, 4, strategy="rows"), PartitionedGAT)
+    with pytest.raises(ValueError):
+        mk(3, 4, strategy="heads")
+    r = mk(4, 8)
+    assert (r.lo, r.hi, r.h_local) == (0, 2, 2) and r.plan["exchange"] == "none"
+    e = r.expected_ms(r.h_local, 16)
+    assert e["forward"]["wire_ms"] == 0 and e["ms_per_step"] > 0 and e["plan"]["mode"] == "heads"
+
+
 def test_chunk_fractions_and_incremental_tables():
     import torch
     from dgnn_amd.dist import PartitionedGAT, chunk_fractions
@@ -175,6 +237,26 @@ def test_partitioned_gat_gpu_two_ranks_unaligned_chunk_cuts(h, f):
     produce the pair (asserted in the worker), agree on it and finish."""
     spec = (12, 4001, 60000, 7)
     check(run_world(2, "gpu", spec, h, f, "halo", 4), spec, h, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,h,f", [(2, 4, 64), (4, 4, 64), (2, 8, 8), (2, 2, 41), (8, 4, 64), (4, 1, 48)])
+def test_head_parallel_gat_gpu_ranks_on_one_card(world, h, f):
+    """The head-parallel runner on the real kernels: gloo ranks sharing cuda:0 (no collective touches the data)."""
+    spec = (12, 4001, 60000, 7)
+    check_heads(run_world(world, "gpuheads", spec, h, f, "auto"), spec, h, f)
+
+
+@pytest.mark.gpu
+def test_head_parallel_gat_nccl_ranks():
+    """One GPU per rank under RCCL (runs wherever two or more GPUs are visible)."""
+    import torch
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one GPU per rank)")
+    spec, h, f = (12, 4001, 60000, 7), 4, 64
+    world = 8 if n_gpu >= 8 else 4 if n_gpu >= 4 else 2      # 8: feature halves, all-reduce inside each head's pair
+    check_heads(run_world(world, "ncclheads", spec, h, f, "auto"), spec, h, f)
 
 
 @pytest.mark.gpu
