@@ -68,9 +68,12 @@ struct BwdParams {
 
 enum { BWD_GAT = 0, BWD_GMM = 1 };
 
-static inline int bwd_group_size(int H, int nnz, bool narrow = false) {
+static inline int bwd_group_size(int H, int nnz, bool narrow = false, int slots = 0) {
   // narrow rows: see narrow_rows() in gather_fast.hpp (4 x 16 backward 9.4 -> 7.2 ms with 128)
-  const int dflt = narrow ? (H <= 4 ? 128 : 64) : (H <= 4 ? 256 : 128);
+  int dflt = narrow ? (H <= 4 ? 128 : 64) : (H <= 4 ? 256 : 128);
+  // round 3 sweep (profiles/r3s_group_size_sweep.txt): one head of 12 .. 16 float4 slots (1 x 48, 1 x 64)
+  // gains 4-5 % with 256; everything else keeps its size (two and four heads lose 10-35 % with 256)
+  if (narrow && H == 1 && slots >= 12 && slots <= 16 && env_int("DGNN_FWD_L_RULE", 1) != 0) dflt = 256;
   const int v = env_int("DGNN_BWD_L", 0);      // tuning override: 64, 128 or 256
   if (!(v == 64 || v == 128 || v == 256)) return shrink_group_for_small_graphs(dflt, nnz, 64);
   return (H > 4 && v > 128) ? 128 : v;

@@ -70,7 +70,7 @@ inline BwdLayout bwd_layout(int m, int n, int nnz, int h, int f, bool need_recom
   w.off_long = o;                                // [0] = counter, [1..] = queue
   o += align_up(sizeof(int) * ((size_t)w.max_long + 1), 256);
   if (w.fast) {
-    w.L = bwd_group_size(bwd_heads_padded(h), nnz, narrow_rows(h, f));
+    w.L = bwd_group_size(bwd_heads_padded(h), nnz, narrow_rows(h, f), h * ((f + 3) / 4));
     w.T = (nnz + w.L - 1) / w.L;
     w.slot_stride = (int)align_up((size_t)h * f + (size_t)h, 4);
     w.off_stat = o;

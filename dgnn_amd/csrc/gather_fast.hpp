@@ -97,12 +97,25 @@ static inline int shrink_group_for_small_graphs(int L, int nnz, int min_L) {
 // products and Reddit shapes, tools/sweep_narrow.sh: 4 x 16 forward 6.9 -> 4.5 ms with 256).
 static inline bool narrow_rows(int H, int F) { return F >= 4 && H * ((F + 3) / 4) < DGNN_WAVE; }
 // Tuning override (multiples of 16): DGNN_FWD_L.
-static inline int fast_group_size(int H, int nnz, bool narrow = false) {
+static inline int fast_group_size(int H, int nnz, bool narrow = false, int slots = 0) {
   int dflt = H <= 4 ? 512 : 256;
   // narrow rows, re-swept with the packed gather (tools/sweep_narrow.sh, round 2): one head 256
   // (products shape 1 x 16: 2.5 -> 2.0 ms, 1 x 48: 3.1 -> 2.8; Reddit shape +2 %), more heads 128
   // (2 x 32: 3.9 -> 3.6, 4 x 16: 4.1 -> 3.8)
   if (narrow) dflt = H == 1 ? 256 : 128;
+  // Round 3, swept again on the one-stream-per-kernel instantiations (profiles/r3s_group_size_sweep.txt,
+  // products shape, scrambled labels): with seven to eight waves per SIMD from registers alone the groups
+  // can be longer -- fewer cut rows to merge, fewer group prologues -- as long as a wave's LDS stage stays
+  // small: a budget of staged floats that grows with the row's float4 slots (wider rows hide more),
+  // divided by the floats staged per edge, to the nearest multiple of 128.  1 x 16 / 1 x 32: 384 (-4 %),
+  // 1 x 48 / 1 x 64: 512 (-5 %), 2 x 16 / 4 x 8: 256 (-13 %), 2 x 32: 384 (-10 %), 2 x 64: 512 (-7 %),
+  // 4 x 16: 256 (-7 %), 4 x 32: 384 (-4 %); eight heads stay at 128 (8 x 8 at 256: +45 %, its softmax
+  // phase needs the waves).  DGNN_FWD_L_RULE=0: the round-2 sizes.
+  if (narrow && slots > 0 && H <= 4 && env_int("DGNN_FWD_L_RULE", 1) != 0) {
+    const float budget = slots <= 8 ? 1300.f : (slots <= 24 ? 1700.f : 2400.f);
+    int l = (int)(budget / ((float)H + 2.5f) / 128.f + 0.5f) * 128;
+    dflt = l < 128 ? 128 : (l > 512 ? 512 : l);
+  }
   const int v = env_int("DGNN_FWD_L", 0);
   if (v >= 16 && v <= 1024 && v % 16 == 0) return v;
   // down to 16 edges per wave: a Cora-sized forward 39 -> 19 us (a group is a chain of dependent

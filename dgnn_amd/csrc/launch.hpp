@@ -28,9 +28,11 @@ struct FwdLayout {
 };
 
 // neg: partial slots also hold the negative-score aggregate and weight sum (GatherParams::out_neg)
-inline FwdLayout fwd_layout(int nnz, int h, int f, bool neg = false) {
+// gat: the fused GAT forward (its narrow shapes take the group sizes of the round-3 sweep; SpMM and GMM keep
+// theirs: the GMM forward on the Reddit shape measured 2.5 % slower with them)
+inline FwdLayout fwd_layout(int nnz, int h, int f, bool neg = false, bool gat = true) {
   FwdLayout w;
-  w.L = fast_group_size(h, nnz, narrow_rows(h, f));
+  w.L = fast_group_size(h, nnz, narrow_rows(h, f), gat ? h * ((f + 3) / 4) : 0);
   w.T = (nnz + w.L - 1) / w.L;
   w.slot_neg = (int)align_up((size_t)h * f + 3 * (size_t)h, 4);
   w.slot_stride = neg ? (int)align_up((size_t)w.slot_neg + (size_t)h * f, 4)

@@ -238,7 +238,7 @@ def test_gat_fuzz_degree_patterns_against_the_oracle(nat, seed, monkeypatch):
     h, f = [(1, 64), (1, 16), (8, 8), (2, 32), (4, 16), (1, 48), (8, 32), (4, 64), (2, 12), (1, 4),
             (1, 47), (4, 41), (3, 7)][seed % 13]
     p = 0.5 if seed % 2 else 0.0
-    monkeypatch.setenv("DGNN_FWD_L", str([16, 32, 64, 128, 256][seed % 5]))
+    monkeypatch.setenv("DGNN_FWD_L", str([16, 32, 64, 128, 256, 384, 512][seed % 7]))
     monkeypatch.setenv("DGNN_BWD_L", str([64, 128, 256][seed % 3]))
     slope = 0.2
     in_feat, attn_row, attn_col, grad = gat_inputs(n, h, f, seed=seed)
