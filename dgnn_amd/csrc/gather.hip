@@ -99,6 +99,11 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
       aligned16(P.edge_mask) && aligned16(P.edge_max) && aligned16(P.edge_sum) &&
       env_int("DGNN_FWD_HT4", steady ? 1 : 0) != 0)
     ht = 4;
+  // 3, 5, 6, 7 heads, rows of one lane pass: the same phase with scalar per-head loads (no alignment needed); until
+  // round 3 they took the run-time-H loops (6 x 8 forward slower than 8 x 8).  DGNN_FWD_HT_ODD=0: A/B runs.
+  if (MODE == MODE_GAT && (P.H == 3 || P.H == 5 || P.H == 6 || P.H == 7) && vec4 && ns == 1 &&
+      env_int("DGNN_FWD_HT_ODD", 1) != 0)
+    ht = P.H;
 #define DGNN_FWD_CASE(VECV, NSV, HTV, STV)                                                     \
   if ((vec4 ? 4 : 1) == VECV && ns == NSV && ht == HTV && steady == STV) {                     \
     if (timing_on())                                                                           \
@@ -118,6 +123,8 @@ int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, 
   if constexpr (MODE == MODE_GAT) {        // (constexpr: SpMM / GMM never instantiate the per-head-vector kernels)
     DGNN_FWD_CASES(1) DGNN_FWD_CASES(2) DGNN_FWD_CASES(8)
     DGNN_FWD_CASE(4, 1, 4, true) DGNN_FWD_CASE(4, 1, 4, false)
+    DGNN_FWD_CASE(4, 1, 3, true) DGNN_FWD_CASE(4, 1, 3, false) DGNN_FWD_CASE(4, 1, 5, true) DGNN_FWD_CASE(4, 1, 5, false)
+    DGNN_FWD_CASE(4, 1, 6, true) DGNN_FWD_CASE(4, 1, 6, false) DGNN_FWD_CASE(4, 1, 7, true) DGNN_FWD_CASE(4, 1, 7, false)
   }
 #undef DGNN_FWD_CASES
 #undef DGNN_FWD_CASE

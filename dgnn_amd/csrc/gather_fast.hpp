@@ -286,8 +286,9 @@ __device__ __forceinline__ void store_row_summed(const GatherParams &P, int row,
   if (active && head == 0) *(float4 *)(P.out + (size_t)row * P.F + lane_off) = tot;
 }
 
-// HT = compile-time head count of the all-heads-at-once softmax phase for 1, 2 or 8 heads
-// (0: run-time H; H == 4 keeps its own float4 path below).
+// HT = compile-time head count of the all-heads-at-once softmax phase (1, 2, 8 heads; 4 for narrow rows; 3, 5, 6, 7
+// for rows of one lane pass, round 3: 6 x 8 forward 6.2 -> 3.6 ms) -- 0: run-time H; wide 4-head rows keep their own
+// float4 path below.
 // STEADY: the instantiation for narrow rows (fewer than 64 float4 slots), whose gather loop is
 // bound by instructions per edge: it adds an unguarded steady-state loop (phase C).  Wide rows
 // keep the kernel without it (the extra path costs the 4 x 64 kernel 10 % through registers).
@@ -304,7 +305,9 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_fast_row_gather(GatherParams P) 
 #ifndef DGNN_FWD_HTB
 #define DGNN_FWD_HTB 2                     // probe builds: 8 x 8 forward 110 VGPRs at once, 86 in fours, 71 in twos
 #endif
-  constexpr int HTB = HTA > DGNN_FWD_HTB ? DGNN_FWD_HTB : HTA;   // heads per block of the softmax phase
+  // heads per block of the softmax phase: blocks must tile the heads exactly (3, 5, 7 heads: all three at once / one by one)
+  constexpr int HTB = HTA <= DGNN_FWD_HTB ? HTA : (HTA % DGNN_FWD_HTB == 0 ? DGNN_FWD_HTB : (HTA <= 4 ? HTA : 1));
+  static_assert(HTA % HTB == 0, "head blocks tile the heads");
   using V = VecT<VEC>;
   using vec_t = typename V::type;
   extern __shared__ __align__(16) float lds_raw[];
