@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SINGLE_GPU_MS = {"products": 21.85, "reddit": 29.4}
 # one rank's head-parallel step timed ALONE on one GPU (bench.py --simulate-rank R/N; nothing is exchanged in that
 # split but one small all-reduce at 8 ranks, so this is a rank's step time): profiles/r3p_dist_head_parallel_ranks.jsonl
-RANK_ALONE_MS = {"products": {2: 11.68, 4: 6.61, 8: 4.24}}
+RANK_ALONE_MS = {"products": {2: 11.33, 4: 6.25, 8: 4.14}}
 # collectives of a bench run take milliseconds: a rank that waits this long has lost a peer
 TORCH_THREADS = torch.get_num_threads()     # (read at start-up: loading the OpenMP oracle later changes what torch reports)
 PG_TIMEOUT = __import__("datetime").timedelta(seconds=int(os.environ.get("DGNN_PG_TIMEOUT", "120")))

@@ -762,7 +762,7 @@ class PartitionedGAT:
 #
 # Which one: on the products shape the row partition moves 35-56 % of the remote rows per pass and
 # is predicted to LOSE at two ranks (one xGMI link), while one rank's step on
-# 2 x 64 / 1 x 64 / 1 x 32 slices takes 11.7 / 6.6 / 4.3 ms against 21.85 ms on one GPU -- the last
+# 2 x 64 / 1 x 64 / 1 x 32 slices takes 11.3 / 6.25 / 4.1 ms against 21.85 ms on one GPU -- the last
 # equal to what a rank of the 8-way row partition computes BEFORE its exchange.  make_gat_runner()
 # therefore picks the slice split whenever heads and features divide and the row partition
 # otherwise; DGNN_DIST_STRATEGY=rows|heads overrides.  The choice depends on (heads, features, world)
