@@ -47,7 +47,7 @@ void launch_fwd_kernel(const GatherParams &P, dim3 grid, size_t lds, hipStream_t
 template <int MODE>
 int launch_fast_gather(GatherParams P, void *workspace, size_t workspace_bytes, hipStream_t st) {
   const bool neg = MODE == MODE_GAT && P.out_neg != nullptr;
-  const FwdLayout w = fwd_layout(P.nnz, P.H, P.F, neg, MODE == MODE_GAT);
+  const FwdLayout w = fwd_layout(P.nnz, P.H, P.F, neg, MODE == MODE_GAT ? 1 : (MODE == MODE_VAL ? 2 : 0));
   if (!workspace || workspace_bytes < w.total) return DGNN_ERR_WORKSPACE;
   P.HF = P.H * P.F;
   P.L = w.L;
@@ -491,7 +491,7 @@ int dgnn_gat_forward_saved(int m, int nnz, int h, int f, float attn_drop, float 
 // ------------------------------------------------------------------------- GE-SpMM / GMM
 size_t dgnn_spmm_csr_workspace_bytes(int m, int nnz, int h, int f) {
   if (m < 0 || nnz < 0 || h <= 0 || f <= 0) return 0;
-  return fwd_layout(nnz, h, f, false, false).total;
+  return fwd_layout(nnz, h, f, false, 2).total;
 }
 
 int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
@@ -519,7 +519,7 @@ int dgnn_spmm_csr(int m, int nnz, int h, int f, const int *row_ptr, const int *c
 
 size_t dgnn_gmm_forward_workspace_bytes(int nodes, int nnz, int kernels, int embed) {
   if (nodes < 0 || nnz < 0 || kernels <= 0 || embed <= 0) return 0;
-  return fwd_layout(nnz, kernels, embed, false, false).total;
+  return fwd_layout(nnz, kernels, embed, false, 0).total;
 }
 
 // float4 rows of at most 64 slots, one lane pass: where the sum over kernels can be folded into the store

@@ -28,11 +28,13 @@ struct FwdLayout {
 };
 
 // neg: partial slots also hold the negative-score aggregate and weight sum (GatherParams::out_neg)
-// gat: the fused GAT forward (its narrow shapes take the group sizes of the round-3 sweep; SpMM and GMM keep
-// theirs: the GMM forward on the Reddit shape measured 2.5 % slower with them)
-inline FwdLayout fwd_layout(int nnz, int h, int f, bool neg = false, bool gat = true) {
+// rule: which narrow shapes take the longer groups of the round-3 sweep (fast_group_size): 1 = the fused GAT
+// forward, all of them; 2 = SpMM, rows of 12 or more float4 slots (1 x 64 -6 %, 2 x 32 -10 %, 4 x 16 -7 %, 2 x 64
+// -4 %; 1 x 16 measured 4 % slower and keeps 256); 0 = GMM, none (Reddit shape: 2.5 % slower with them)
+inline FwdLayout fwd_layout(int nnz, int h, int f, bool neg = false, int rule = 1) {
   FwdLayout w;
-  w.L = fast_group_size(h, nnz, narrow_rows(h, f), gat ? h * ((f + 3) / 4) : 0);
+  const int slots = h * ((f + 3) / 4);
+  w.L = fast_group_size(h, nnz, narrow_rows(h, f), (rule == 1 || (rule == 2 && slots >= 12)) ? slots : 0);
   w.T = (nnz + w.L - 1) / w.L;
   w.slot_neg = (int)align_up((size_t)h * f + 3 * (size_t)h, 4);
   w.slot_stride = neg ? (int)align_up((size_t)w.slot_neg + (size_t)h * f, 4)
