@@ -205,6 +205,117 @@ __global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_fast(int v, int nnz, int H
   for (int i = lane; i < cnt * H; i += DGNN_WAVE) out[(size_t)e0 * H + i] = dbuf[i];
 }
 
+// Narrow rows (a padded row of at most 16 float4 lanes: 1 x 16, 1 x 64, 4 x 16, 8 x 8, 1 x 47 ...): the walk above
+// handles ONE edge per load step, so 48 .. 60 of the 64 lanes idle and the kernel is bound by instructions per
+// edge (1 x 16 on the products shape: 3.4 ms against 0.95 ms for the SpMM of the same rows).  Here the wave's
+// lanes form G = 64 / S groups of S lanes (S = padded heads x lanes per head, at least 4); group g takes edge
+// p0 + g of a step and loads its own slice of BOTH operand rows (consecutive edges share the A row: those
+// loads hit the same lines), U = 4 steps in flight.  Same per-lane FMA chain and the same DPP reduction inside
+// a head's lanes as k_sddmm_fast: identical bits.
+template <int S>
+__global__ __launch_bounds__(DGNN_BLOCK) void k_sddmm_packed(int v, int nnz, int H, int F, int HF, int fv,
+                                                             const int *__restrict__ row_ptr,
+                                                             const int *__restrict__ col_ind,
+                                                             const float *__restrict__ A,
+                                                             const float *__restrict__ B,
+                                                             float *__restrict__ out) {
+  extern __shared__ __align__(16) float lds_raw[];
+  constexpr int L = DGNN_SDDMM_L;
+  constexpr int G = DGNN_WAVE / S;
+  constexpr int U = DGNN_SDDMM_U;
+  const int wib = wave_in_block();
+  const int lane = lane_id();
+  const int T = (nnz + L - 1) / L;
+  const int t = uniform_i32(blockIdx.x * DGNN_WAVES_PER_BLOCK + wib);
+  if (t >= T) return;
+  const size_t per_wave = (size_t)L * 2 + (size_t)L * H;
+  int *rowE = (int *)(lds_raw + (size_t)wib * per_wave);   // [L] row of edge p
+  int *colE = rowE + L;                                    // [L] column of edge p
+  float *dbuf = (float *)(colE + L);                       // [L][H]
+  const int e0 = t * L;
+  const int e1 = min(e0 + L, nnz);
+  const int cnt = e1 - e0;
+  for (int p = lane; p < cnt; p += DGNN_WAVE) colE[p] = col_ind[e0 + p];
+  // first row of the group: largest r with row_ptr[r] <= e0 (64-ary search, ~4 rounds)
+  int lo = 0, hi = v;
+  while (hi - lo > 1) {
+    const int step = (hi - lo + DGNN_WAVE - 1) / DGNN_WAVE;
+    const long long idx = (long long)lo + (long long)(lane + 1) * step;
+    const bool ok = (idx < hi) && (row_ptr[idx] <= e0);
+    const int c = __popcll(__ballot(ok));
+    const int nlo = lo + c * step;
+    const long long nhi = (long long)lo + (long long)(c + 1) * step;
+    lo = nlo;
+    hi = (int)(nhi < hi ? nhi : hi);
+  }
+  // rows of the group, one lane per row; a row longer than 64 edges is filled by the whole wave
+  {
+    int rbase = lo;
+    while (true) {
+      const int r = rbase + lane;
+      int rs = 0x7fffffff, re = 0x7fffffff;
+      if (r < v) {
+        rs = row_ptr[r];
+        re = row_ptr[r + 1];
+      }
+      const int a = max(rs, e0) - e0;
+      const int b = (re < e1 ? re : e1) - e0;
+      const bool nonempty = (r < v) && (rs < e1) && (b > a);
+      const bool is_long = nonempty && (b - a) > DGNN_WAVE;
+      if (nonempty && !is_long)
+        for (int p = a; p < b; ++p) rowE[p] = r;
+      unsigned long long lg = __ballot(is_long);
+      while (lg != 0ull) {                                  // hub rows: every lane writes a share
+        const int src = uniform_i32(__ffsll((long long)lg) - 1);
+        lg &= lg - 1ull;
+        const int ra = bcast_i32(a, src), rb = bcast_i32(b, src), rr = bcast_i32(r, src);
+        for (int p = ra + lane; p < rb; p += DGNN_WAVE) rowE[p] = rr;
+      }
+      const bool reached_end = (r >= v - 1) || (re >= e1);
+      if (__ballot(reached_end) != 0ull) break;
+      rbase += DGNN_WAVE;
+    }
+  }
+  wave_lds_sync();
+
+  const int ls = lane % S, g = lane / S;
+  const int hd = ls / fv, q = ls % fv;
+  const bool active = hd < H && q * 4 < F;
+  const size_t lane_off = active ? (size_t)hd * F + (size_t)slot4_off(q, F) : 0;
+  const int dup = slot4_dup(q, F);
+  const bool leader = active && q == 0;
+  float4 ra_[U], rb_[U];
+  auto issue = [&](int p0, float4 &xa, float4 &xb) {
+    const int p = min(p0 + g, cnt - 1);
+    const int r = rowE[p], c = colE[p];
+    xa = ld4u(A + (size_t)r * HF + lane_off);
+    xb = ld4u(B + (size_t)c * HF + lane_off);
+  };
+  auto consume = [&](int p0, const float4 &xa, const float4 &xb) {
+    const int p = p0 + g;
+    const float4 u = slot4_mask(xa, dup);
+    float dot = active ? fmaf(xb.x, u.x, fmaf(xb.y, u.y, fmaf(xb.z, u.z, xb.w * u.w))) : 0.f;
+    dot = group_reduce(dot, fv, OpSum());
+    if (leader && p < cnt) dbuf[(size_t)p * H + hd] = dot;
+  };
+#pragma unroll
+  for (int i = 0; i < U; ++i)
+    if (i * G < cnt) issue(i * G, ra_[i], rb_[i]);
+  for (int p0 = 0; p0 < cnt; p0 += U * G) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int pi = p0 + i * G;
+      if (pi < cnt) {
+        const float4 xa = ra_[i], xb = rb_[i];
+        if (pi + U * G < cnt) issue(pi + U * G, ra_[i], rb_[i]);
+        consume(pi, xa, xb);
+      }
+    }
+  }
+  wave_lds_sync();
+  for (int i = lane; i < cnt * H; i += DGNN_WAVE) out[(size_t)e0 * H + i] = dbuf[i];
+}
+
 // out[i,:] = in[permute[i],:]   (mhtranspose_kernel.cu:6-26)
 __global__ void k_mhtranspose(long long total, int H, const int *__restrict__ permute,
                               const float *__restrict__ in, float *__restrict__ out) {
@@ -647,7 +758,21 @@ int dgnn_mhsddmm(int v, int f, int h, int nnz, const int *row_ptr, const int *co
   int fv = 1;
   while (fv < (f + vec - 1) / vec) fv <<= 1;
   const bool fast = fv <= DGNN_WAVE && h <= 8 && v < (1 << 30) && !(fg && fg[0] == '1');
-  if (fast) {
+  // narrow float4 rows: several edges per load step (k_sddmm_packed; DGNN_SDDMM_PACK=0: A/B runs)
+  int hp = 1;
+  while (hp < h) hp <<= 1;
+  const int pack_s = (vec == 4 && hp * fv <= 16) ? (hp * fv < 4 ? 4 : hp * fv) : 0;
+  const char *pk = getenv("DGNN_SDDMM_PACK");
+  if (fast && pack_s != 0 && !(pk && pk[0] == '0')) {
+    const int T = (nnz + DGNN_SDDMM_L - 1) / DGNN_SDDMM_L;
+    const size_t lds = (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)DGNN_SDDMM_L * 2 + (size_t)DGNN_SDDMM_L * h) * sizeof(float);
+#define DGNN_SDDMM_PACKED(SV)                                                                                     \
+  if (pack_s == SV)                                                                                               \
+    hipLaunchKernelGGL((k_sddmm_packed<SV>), dim3(blocks_for_waves(T)), dim3(DGNN_BLOCK), lds, (hipStream_t)stream, \
+                       v, nnz, h, f, hf, fv, row_ptr, col_ind, grad, feature, out);
+    DGNN_SDDMM_PACKED(4) DGNN_SDDMM_PACKED(8) DGNN_SDDMM_PACKED(16)
+#undef DGNN_SDDMM_PACKED
+  } else if (fast) {
     const int T = (nnz + DGNN_SDDMM_L - 1) / DGNN_SDDMM_L;
     const size_t lds = (size_t)DGNN_WAVES_PER_BLOCK * ((size_t)DGNN_SDDMM_L * 3 + (size_t)DGNN_SDDMM_L * h) * sizeof(float);
     const int hpp = DGNN_WAVE / fv;
