@@ -114,7 +114,7 @@ class FusedGATFunction(torch.autograd.Function):
         attn_row = attn_row.contiguous()
         attn_col = attn_col.contiguous()
         ctx.f = in_feat.size(2)
-        in_feat = _pad4(in_feat.contiguous())          # odd widths run padded (see _pad4)
+        in_feat = _pad4(in_feat.contiguous())          # rows narrower than four floats run padded (see _pad4)
         out_feat, edge_max, edge_sum, edge_mask, ctx.seed, out_neg, a_neg = _forward_with_dropout(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
@@ -163,7 +163,7 @@ class FusedGATFromFeatFunction(torch.autograd.Function):
             scores = (attn_l * feat).sum(-1), (attn_r * feat).sum(-1)
         attn_row, attn_col = scores
         ctx.f = feat.size(2)
-        feat_p = _pad4(feat)                              # odd widths run padded (see _pad4)
+        feat_p = _pad4(feat)                              # rows narrower than four floats run padded (see _pad4)
         out_feat, edge_max, edge_sum, edge_mask, ctx.seed, out_neg, a_neg = _forward_with_dropout(
             attn_row, attn_col, row_ptr, col_ind, negative_slope, feat_p, attn_drop)
         ctx.save_for_backward(row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,

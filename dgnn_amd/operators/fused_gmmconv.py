@@ -23,7 +23,7 @@ class GmmFuseFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma):
         ctx.f = node_feat.size(2)
-        node_feat, pseudo = pad4(node_feat.contiguous()), pseudo.contiguous()   # odd widths run padded
+        node_feat, pseudo = pad4(node_feat.contiguous()), pseudo.contiguous()   # rows narrower than four floats run padded
         mu, sigma = mu.contiguous(), sigma.contiguous()
         out = gmm.gmmconv(rowptr, colind, node_feat, pseudo, mu, sigma)
         ctx.save_for_backward(rowptr, colind, colptr, rowind, permute, node_feat, pseudo, mu, sigma)

@@ -19,7 +19,7 @@ class SpMMCsrFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rowptr, colind, colptr, rowind, permute, edge_val, in_feat):
         ctx.f = in_feat.size(2)
-        edge_val, in_feat = edge_val.contiguous(), pad4(in_feat.contiguous())   # odd widths run padded
+        edge_val, in_feat = edge_val.contiguous(), pad4(in_feat.contiguous())   # rows narrower than four floats run padded
         ctx.save_for_backward(rowptr, colind, colptr, rowind, permute, edge_val, in_feat)
         return unpad(spmm.spmm_csr(rowptr, colind, edge_val, in_feat), ctx.f)
 
