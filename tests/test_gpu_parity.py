@@ -233,10 +233,10 @@ def test_gat_fuzz_degree_patterns_against_the_oracle(nat, seed, monkeypatch):
     if seed % 4 == 1:
         deg[: n // 3] = rng.integers(1, 5, n // 3)               # a long run of very short rows
     g = degree_graph(n, [int(d) for d in deg], seed)
-    # 13 shapes against the periods 2 / 3 / 5 of the other choices: every combination comes up; odd widths (float4
+    # 17 shapes against the periods 2 / 3 / 5 / 7 of the other choices: every combination comes up; odd widths (float4
     # lanes at any dword alignment, overlapping last slot) included
     h, f = [(1, 64), (1, 16), (8, 8), (2, 32), (4, 16), (1, 48), (8, 32), (4, 64), (2, 12), (1, 4),
-            (1, 47), (4, 41), (3, 7)][seed % 13]
+            (1, 47), (4, 41), (3, 7), (6, 8), (5, 12), (7, 4), (3, 16)][seed % 17]
     p = 0.5 if seed % 2 else 0.0
     monkeypatch.setenv("DGNN_FWD_L", str([16, 32, 64, 128, 256, 384, 512][seed % 7]))
     monkeypatch.setenv("DGNN_BWD_L", str([64, 128, 256][seed % 3]))
